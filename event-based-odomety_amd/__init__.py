@@ -1,0 +1,369 @@
+"""event-based-odomety_amd — MI355X (gfx950) implementation of the motion-compensated
+event-warping path of nurlanov-zh/event-based-odomety.
+
+The product is the C-ABI library ``libebo_hip.so`` (include/ebo.h) plus the C++
+façade in ``include/feature_tracker``.  This module is only the ctypes plumbing the
+Python tests and bench.py use to call that ABI; it contains no compute and no CPU
+fallback.  Importing it never needs a GPU; creating a Context does.
+
+The directory name has a hyphen (the upstream repository name), so import it with
+``importlib.import_module("event-based-odomety_amd")``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libebo_hip.so")
+HEADER_PATH = os.path.join(ROOT, "include", "ebo.h")
+
+OK = 0
+ERR_ARG, ERR_HIP, ERR_RANGE, ERR_STATE, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SOLVER = (
+    -1, -2, -3, -4, -5, -6, -7)
+LOSS_EDGE, LOSS_VARIANCE = 0, 1
+GRAD_JET, GRAD_CENTRAL = 0, 1
+SOLVE_GLOBAL, SOLVE_INDEPENDENT = 0, 1
+COUNT_INTEGRATED, COUNT_WARPED, COUNT_FIELD = 0, 1, 2
+
+# numpy mirror of ebo_event (== common::EventSample, 24 bytes)
+EVENT_DTYPE = np.dtype(
+    [("x", "<i4"), ("y", "<i4"), ("sign", "<i4"), ("reserved", "<i4"), ("t_us", "<i8")]
+)
+
+
+class FunctorConsts(C.Structure):
+    _fields_ = [
+        ("max_possible_residual", C.c_double),
+        ("sigma_compensate", C.c_double),
+        ("kernel_compensate", C.c_int32),
+        ("kernel_st", C.c_int32),
+        ("sigma_st", C.c_double),
+        ("kernel_nms", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("image_w", C.c_int32),
+        ("image_h", C.c_int32),
+        ("patch_w", C.c_int32),
+        ("patch_h", C.c_int32),
+        ("tv_weight", C.c_double),
+        ("tv_huber", C.c_double),
+        ("scale", C.c_double),
+        ("min_events", C.c_uint32),
+        ("loss", C.c_int32),
+        ("grad", C.c_int32),
+        ("reserved", C.c_int32),
+        ("fd_step", C.c_double),
+        ("k", FunctorConsts),
+        ("max_events", C.c_uint64),
+        ("max_windows", C.c_int32),
+        ("reserved2", C.c_int32),
+    ]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("use_nonmonotonic", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double),
+        ("max_radius", C.c_double),
+        ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("max_consecutive_nonmonotonic", C.c_int32),
+        ("max_consecutive_invalid", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("mode", C.c_int32),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("num_evals_cost", C.c_int32),
+        ("num_evals_jac", C.c_int32),
+        ("termination", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+    ]
+
+
+class EboError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ebo error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libebo_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: run __graft_entry__.build() (hipcc). "
+                "This package has no CPU path." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ebo_version.restype = C.c_char_p
+        _lib.ebo_last_error.restype = C.c_char_p
+        _lib.ebo_last_error.argtypes = [C.c_void_p]
+        _lib.ebo_destroy.restype = None
+        _lib.ebo_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def version():
+    return lib().ebo_version().decode()
+
+
+def device_count():
+    n = C.c_int()
+    lib().ebo_device_count(C.byref(n))
+    return n.value
+
+
+def default_params(**kw):
+    p = Params()
+    lib().ebo_default_params(C.byref(p))
+    for key, val in kw.items():
+        if not hasattr(p, key):
+            raise AttributeError(key)
+        setattr(p, key, val)
+    return p
+
+
+def default_solver(**kw):
+    o = SolverOpts()
+    lib().ebo_default_solver(C.byref(o))
+    for key, val in kw.items():
+        if not hasattr(o, key):
+            raise AttributeError(key)
+        setattr(o, key, val)
+    return o
+
+
+def shard_range(n_units, rank, world):
+    b, e = C.c_int(), C.c_int()
+    rc = lib().ebo_shard_range(int(n_units), int(rank), int(world), C.byref(b), C.byref(e))
+    if rc:
+        raise EboError(rc, "bad shard arguments")
+    return b.value, e.value
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_events(x, y, t_us, sign=None):
+    ev = np.zeros(len(x), dtype=EVENT_DTYPE)
+    ev["x"] = x
+    ev["y"] = y
+    ev["t_us"] = t_us
+    ev["sign"] = 1 if sign is None else sign
+    return ev
+
+
+class Context:
+    """Owns one ebo_ctx (one device, one stream).  Mirrors include/ebo.h 1:1."""
+
+    def __init__(self, params=None, **kw):
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params(**kw)
+        rc = lib().ebo_create(C.byref(self.params), C.byref(self._h))
+        if rc:
+            raise EboError(rc, lib().ebo_last_error(None).decode())
+        npx, npy = C.c_int(), C.c_int()
+        self._check(lib().ebo_grid(self._h, C.byref(npx), C.byref(npy)))
+        self.npx, self.npy = npx.value, npy.value
+        self.P = self.npx * self.npy
+        self.n_windows = 0
+
+    def _check(self, rc):
+        if rc:
+            raise EboError(rc, lib().ebo_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().ebo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- setup ---------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._check(lib().ebo_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
+    def synchronize(self):
+        self._check(lib().ebo_synchronize(self._h))
+
+    def patch_rect(self, px, py):
+        v = [C.c_int() for _ in range(4)]
+        self._check(lib().ebo_patch_rect(self._h, int(px), int(py), *[C.byref(a) for a in v]))
+        return tuple(a.value for a in v)
+
+    def set_window(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self._check(lib().ebo_set_window(self._h, _vp(ev), C.c_size_t(len(ev))))
+        self.n_windows = 1
+
+    def set_windows(self, ev, offsets):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        self._check(lib().ebo_set_windows(self._h, _vp(ev), _vp(offsets), int(n)))
+        self.n_windows = n
+
+    def window_info(self, w=0):
+        t, n = C.c_int64(), C.c_uint64()
+        self._check(lib().ebo_window_info(self._h, int(w), C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    def patch_info(self, p, w=0):
+        n, a, t = C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(lib().ebo_patch_info(self._h, int(w), int(p), C.byref(n), C.byref(a), C.byref(t)))
+        return n.value, bool(a.value), t.value
+
+    # -- objective -----------------------------------------------------------
+    def eval(self, flows, want_jac=True):
+        flows = np.ascontiguousarray(flows, dtype=np.float64).reshape(self.n_windows, self.P, 2)
+        r = np.zeros((self.n_windows, self.P))
+        J = np.zeros((self.n_windows, self.P, 2)) if want_jac else None
+        self._check(lib().ebo_eval(self._h, _dp(flows), _dp(r), _dp(J) if want_jac else None))
+        return r, J
+
+    def eval_device(self, d_flows, want_jac, d_out):
+        self._check(lib().ebo_eval_device(
+            self._h, C.c_void_p(int(d_flows)), int(want_jac), C.c_void_p(int(d_out))))
+
+    def contrast_image(self, patch, flow, channels=3, window=0):
+        x, y, w, h = self.patch_rect(patch % self.npx, patch // self.npx)
+        flow = np.ascontiguousarray(flow, dtype=np.float64)
+        img = np.zeros((channels, 3 * h, 3 * w))
+        self._check(lib().ebo_contrast_image(
+            self._h, int(window), int(patch), _dp(flow), int(channels), _dp(img)))
+        return img
+
+    # -- solve ---------------------------------------------------------------
+    def solve(self, opts=None, **kw):
+        opts = opts if opts is not None else default_solver(**kw)
+        flows = np.zeros((self.n_windows, self.P, 2))
+        summ = (Summary * self.n_windows)()
+        self._check(lib().ebo_solve(self._h, C.byref(opts), _dp(flows), summ))
+        return flows, list(summ)
+
+    def solve_device(self, opts, d_flows_out, d_stats=0):
+        self._check(lib().ebo_solve_device(
+            self._h, C.byref(opts), C.c_void_p(int(d_flows_out)),
+            C.c_void_p(int(d_stats)) if d_stats else None))
+
+    # -- count images --------------------------------------------------------
+    def count_image(self, mode, aux=None):
+        img = np.zeros((self.n_windows, self.params.image_h, self.params.image_w))
+        a = None
+        if mode == COUNT_WARPED:
+            aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.n_windows, self.P, 2)
+            a = _vp(aux)
+        elif mode == COUNT_FIELD:
+            aux = np.ascontiguousarray(aux, dtype=np.float32).reshape(
+                self.n_windows, self.params.image_h, self.params.image_w, 2)
+            a = _vp(aux)
+        self._check(lib().ebo_count_image(self._h, int(mode), a, _dp(img)))
+        return img
+
+    def count_image_device(self, mode, d_aux, d_image):
+        self._check(lib().ebo_count_image_device(
+            self._h, int(mode), C.c_void_p(int(d_aux)) if d_aux else None,
+            C.c_void_p(int(d_image))))
+
+    def compensate_events_contrast(self, ev, opts=None, want_image=True):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        opts = opts if opts is not None else default_solver()
+        flows = np.zeros((self.P, 2))
+        img = np.zeros((self.params.image_h, self.params.image_w)) if want_image else None
+        s = Summary()
+        self._check(lib().ebo_compensate_events_contrast(
+            self._h, _vp(ev), C.c_size_t(len(ev)), C.byref(opts), _dp(flows),
+            _dp(img) if want_image else None, C.byref(s)))
+        self.n_windows = 1
+        return flows, img, s
+
+    # -- tracked-feature patches (Patch::integrate*) --------------------------
+    def patch_integrate(self, ev, offsets, rects):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        n = len(rects)
+        sizes = [int(r[3]) * int(r[2]) for r in rects]
+        noff = np.zeros(n, dtype=np.uint64)
+        noff[1:] = np.cumsum(sizes[:-1])
+        nabla = np.zeros(int(sum(sizes)))
+        cur = np.zeros(n, dtype=np.int64)
+        last = np.zeros(n, dtype=np.int64)
+        self._check(lib().ebo_patch_integrate(
+            self._h, _vp(ev), _vp(offsets), n, _dp(rects), _vp(noff), _dp(nabla), _vp(cur), _vp(last)))
+        imgs = [nabla[int(noff[i]):int(noff[i]) + sizes[i]].reshape(int(rects[i][3]), int(rects[i][2]))
+                for i in range(n)]
+        return imgs, cur, last
+
+    def patch_integrate_mc(self, ev, offsets, rects, traj, mid_time, init=None):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        traj = np.ascontiguousarray(traj, dtype=np.float64).reshape(-1, 6)
+        mid_time = np.ascontiguousarray(mid_time, dtype=np.int64)
+        n = len(rects)
+        sizes = [int(r[3]) * int(r[2]) for r in rects]
+        noff = np.zeros(n, dtype=np.uint64)
+        noff[1:] = np.cumsum(sizes[:-1])
+        nabla = np.zeros(int(sum(sizes))) if init is None else np.ascontiguousarray(init, dtype=np.float64).copy()
+        upd = np.zeros(n, dtype=np.int32)
+        self._check(lib().ebo_patch_integrate_mc(
+            self._h, _vp(ev), _vp(offsets), n, _dp(rects), _dp(traj), _vp(mid_time), _vp(noff),
+            _dp(nabla), _vp(upd)))
+        imgs = [nabla[int(noff[i]):int(noff[i]) + sizes[i]].reshape(int(rects[i][3]), int(rects[i][2]))
+                for i in range(n)]
+        return imgs, upd
+
+    # -- timing --------------------------------------------------------------
+    def timer_begin(self):
+        self._check(lib().ebo_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._check(lib().ebo_timer_end(self._h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,1437 @@
+// ebo_api.cpp — host side of libebo_hip.so: context, window bucketing/packing,
+// kernel launches and the extern "C" entry points declared in include/ebo.h.
+// There is no CPU compute path here: every objective value, Jacobian, solved flow
+// and count image comes from the HIP kernels in ebo_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ebo.h"
+#include "ebo_internal.h"
+#include "host_lm.h"
+
+using namespace ebo;
+
+namespace
+{
+thread_local std::string g_create_error;
+
+size_t env_size(const char* name, size_t dflt)
+{
+	const char* v = std::getenv(name);
+	if (!v || !*v)
+	{
+		return dflt;
+	}
+	return static_cast<size_t>(std::strtoull(v, nullptr, 10));
+}
+
+struct WindowInfo
+{
+	int64_t t_ref;
+	uint64_t n_events;
+};
+}  // namespace
+
+struct ebo_ctx
+{
+	ebo_params prm;
+	int npx = 0, npy = 0, P = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	std::string err;
+
+	size_t cap_events = 0;
+	int cap_windows = 0;
+	int n_windows = 0;
+
+	uint64_t* d_events = nullptr;
+	Unit* d_units = nullptr;
+	double* d_flows = nullptr;
+	double* d_out = nullptr;
+	double* d_partials = nullptr;
+	size_t partials_cap = 0;
+	int32_t* d_counts = nullptr;
+	double* d_image = nullptr;
+	void* d_aux = nullptr;
+	size_t aux_cap = 0;
+	int32_t* d_stats = nullptr;
+	void* d_scratch = nullptr;  // patch-integrate staging
+	size_t scratch_cap = 0;
+
+	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window
+	std::vector<int64_t> unit_tref;
+	std::vector<WindowInfo> windows;
+	std::vector<uint64_t> h_packed;
+	std::vector<double> h_out;
+
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	int max_rw = 0, max_rh = 0;
+
+	int fail(int code, const std::string& msg)
+	{
+		err = msg;
+		return code;
+	}
+	int hip(hipError_t e, const char* what)
+	{
+		if (e == hipSuccess)
+		{
+			return EBO_OK;
+		}
+		err = std::string(what) + ": " + hipGetErrorString(e);
+		return EBO_ERR_HIP;
+	}
+};
+
+namespace
+{
+EvalConsts make_consts(const ebo_ctx* c)
+{
+	EvalConsts k;
+	const double sig = c->prm.k.sigma_compensate;
+	k.scale = c->prm.scale;
+	k.max_res = c->prm.k.max_possible_residual;
+	k.norm = 1.0 / ((2 * M_PI) * (sig * sig));
+	k.hs = -0.5 / (sig * sig);
+	k.inv_sigsq = 1.0 / (sig * sig);
+	k.image_w = c->prm.image_w;
+	k.image_h = c->prm.image_h;
+	k.patch_w = c->prm.patch_w;
+	k.patch_h = c->prm.patch_h;
+	k.npx = c->npx;
+	k.npy = c->npy;
+	return k;
+}
+
+void rect_of(const ebo_ctx* c, int px, int py, int& x, int& y, int& w, int& h)
+{
+	// feature_detector.cpp:332-346
+	x = px * c->prm.patch_w;
+	y = py * c->prm.patch_h;
+	w = c->prm.patch_w;
+	h = c->prm.patch_h;
+	if (px == c->npx - 1)
+	{
+		w = c->prm.image_w - px * c->prm.patch_w;
+	}
+	if (py == c->npy - 1)
+	{
+		h = c->prm.image_h - py * c->prm.patch_h;
+	}
+}
+
+// int32 truncation of the mean of two timestamps (contrast_functor.h:18-20,
+// feature_detector.cpp:305-306).  Outside int32 the reference's cast is undefined.
+bool mid_timestamp(int64_t a, int64_t b, int64_t& out)
+{
+	const double half = static_cast<double>(a + b) * 0.5;
+	if (!(half > -2147483648.0 && half < 2147483648.0))
+	{
+		return false;
+	}
+	out = static_cast<int64_t>(static_cast<int32_t>(half));
+	return true;
+}
+
+const size_t kLdsBudget = 160 * 1024;
+const size_t kRedBytes = 16 * 8 * sizeof(double);
+
+size_t lds_for(int channels, int tiles, int rw, int rh)
+{
+	const int rows = (3 * rh + tiles - 1) / tiles;
+	return static_cast<size_t>(channels) * rows * 3 * rw * sizeof(double) + kRedBytes;
+}
+
+int min_tiles(int channels, int rw, int rh, size_t budget)
+{
+	for (int t = 1; t <= 3 * rh; ++t)
+	{
+		if (lds_for(channels, t, rw, rh) <= budget)
+		{
+			return t;
+		}
+	}
+	return -1;
+}
+
+int ensure_partials(ebo_ctx* c, size_t n)
+{
+	if (n <= c->partials_cap)
+	{
+		return EBO_OK;
+	}
+	if (c->d_partials)
+	{
+		hipFree(c->d_partials);
+		c->d_partials = nullptr;
+		c->partials_cap = 0;
+	}
+	int rc = c->hip(hipMalloc(&c->d_partials, n * sizeof(double)), "hipMalloc partials");
+	if (rc == EBO_OK)
+	{
+		c->partials_cap = n;
+	}
+	return rc;
+}
+
+int ensure_aux(ebo_ctx* c, size_t bytes)
+{
+	if (bytes <= c->aux_cap)
+	{
+		return EBO_OK;
+	}
+	if (c->d_aux)
+	{
+		hipFree(c->d_aux);
+		c->d_aux = nullptr;
+		c->aux_cap = 0;
+	}
+	int rc = c->hip(hipMalloc(&c->d_aux, bytes), "hipMalloc aux");
+	if (rc == EBO_OK)
+	{
+		c->aux_cap = bytes;
+	}
+	return rc;
+}
+
+int ensure_scratch(ebo_ctx* c, size_t bytes)
+{
+	if (bytes <= c->scratch_cap)
+	{
+		return EBO_OK;
+	}
+	if (c->d_scratch)
+	{
+		hipFree(c->d_scratch);
+		c->d_scratch = nullptr;
+		c->scratch_cap = 0;
+	}
+	int rc = c->hip(hipMalloc(&c->d_scratch, bytes), "hipMalloc scratch");
+	if (rc == EBO_OK)
+	{
+		c->scratch_cap = bytes;
+	}
+	return rc;
+}
+
+// Evaluation geometry.  tiles: row tiles per unit (parallel workgroups).  More
+// tiles = more workgroups and less LDS each; the events of a unit are re-read
+// (from L2) by each of its tiles.  EBO_EVAL_TILES / EBO_EVAL_BLOCK override.
+int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
+{
+	const size_t budget = env_size("EBO_LDS_BUDGET", kLdsBudget);
+	const int fit = min_tiles(channels, c->max_rw, c->max_rh, budget);
+	if (fit < 0)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "patch too wide for LDS row tiling");
+	}
+	int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
+	if (t <= 0)
+	{
+		t = fit;
+		const int nUnits = c->n_windows * c->P;
+		// fill the chip (256 CUs) when there are few units, but keep >= 16 rows per tile
+		while (nUnits * t < 512 && (3 * c->max_rh) / (t + 1) >= 16)
+		{
+			++t;
+		}
+	}
+	t = std::max(t, fit);
+	tiles = t;
+	block = static_cast<int>(env_size("EBO_EVAL_BLOCK", 256));
+	if (block < 64 || block > 1024 || (block & 63))
+	{
+		return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,1024]");
+	}
+	lds = lds_for(channels, t, c->max_rw, c->max_rh);
+	return EBO_OK;
+}
+
+int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out)
+{
+	if (c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	if (c->prm.loss != EBO_LOSS_VARIANCE)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED,
+					   "edge loss is not built on the device yet; use EBO_LOSS_VARIANCE");
+	}
+	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
+	EvalLaunch L;
+	L.d_events = c->d_events;
+	L.d_units = c->d_units;
+	L.n_units = static_cast<int>(c->units.size());
+	L.d_flows = d_flows;
+	L.n_flow = c->n_windows * c->P;
+	L.flow_sets = central ? 5 : 1;
+	L.channels = (want_jac && !central) ? 3 : 1;
+	L.fd_step = central ? c->prm.fd_step : 0.0;
+	int rc = eval_geometry(c, L.channels, L.tiles, L.block, L.lds_bytes);
+	if (rc)
+	{
+		return rc;
+	}
+	rc = ensure_partials(c, static_cast<size_t>(L.flow_sets) * L.n_units * L.tiles * kPartialStride);
+	if (rc)
+	{
+		return rc;
+	}
+	L.d_partials = c->d_partials;
+	L.d_out = d_out;
+	L.c = make_consts(c);
+	if (launch_eval_variance(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "eval launch");
+	}
+	return EBO_OK;
+}
+
+int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac)
+{
+	const size_t nf = static_cast<size_t>(c->n_windows) * c->P;
+	int rc = c->hip(hipMemcpyAsync(c->d_flows, flows, nf * 2 * sizeof(double),
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D flows");
+	if (rc)
+	{
+		return rc;
+	}
+	rc = run_eval_device(c, c->d_flows, jac != nullptr, c->d_out);
+	if (rc)
+	{
+		return rc;
+	}
+	c->h_out.resize(nf * 3);
+	rc = c->hip(hipMemcpyAsync(c->h_out.data(), c->d_out, nf * 3 * sizeof(double),
+							   hipMemcpyDeviceToHost, c->stream),
+				"D2H out");
+	if (rc)
+	{
+		return rc;
+	}
+	rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	if (rc)
+	{
+		return rc;
+	}
+	for (size_t i = 0; i < nf; ++i)
+	{
+		r[i] = c->h_out[3 * i];
+		if (jac)
+		{
+			jac[2 * i] = c->h_out[3 * i + 1];
+			jac[2 * i + 1] = c->h_out[3 * i + 2];
+		}
+	}
+	return EBO_OK;
+}
+
+SolveConsts make_solve_consts(const ebo_solver_opts* o)
+{
+	SolveConsts s;
+	s.max_num_iterations = o->max_num_iterations;
+	s.max_nonmono = o->use_nonmonotonic ? o->max_consecutive_nonmonotonic : 0;
+	s.max_invalid = o->max_consecutive_invalid;
+	s.jacobi_scaling = o->jacobi_scaling;
+	s.function_tolerance = o->function_tolerance;
+	s.gradient_tolerance = o->gradient_tolerance;
+	s.parameter_tolerance = o->parameter_tolerance;
+	s.initial_radius = o->initial_radius;
+	s.max_radius = o->max_radius;
+	s.min_radius = o->min_radius;
+	s.min_relative_decrease = o->min_relative_decrease;
+	s.min_lm_diagonal = o->min_lm_diagonal;
+	s.max_lm_diagonal = o->max_lm_diagonal;
+	return s;
+}
+
+int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, int32_t* d_stats)
+{
+	if (c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	if (c->prm.loss != EBO_LOSS_VARIANCE)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "device solver is built for EBO_LOSS_VARIANCE");
+	}
+	if (c->prm.grad != EBO_GRAD_JET)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "device solver is built for EBO_GRAD_JET");
+	}
+	SolveLaunch L;
+	L.d_events = c->d_events;
+	L.d_units = c->d_units;
+	L.n_units = static_cast<int>(c->units.size());
+	const size_t budget = env_size("EBO_LDS_BUDGET", kLdsBudget);
+	L.tiles3 = min_tiles(3, c->max_rw, c->max_rh, budget);
+	L.tiles1 = min_tiles(1, c->max_rw, c->max_rh, budget);
+	if (L.tiles3 < 0 || L.tiles1 < 0)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "patch too wide for LDS row tiling");
+	}
+	L.tiles3 = std::max<int>(L.tiles3, static_cast<int>(env_size("EBO_SOLVE_TILES3", 0)));
+	L.tiles1 = std::max<int>(L.tiles1, static_cast<int>(env_size("EBO_SOLVE_TILES1", 0)));
+	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", 256));
+	L.lds_bytes = std::max(lds_for(3, L.tiles3, c->max_rw, c->max_rh),
+						   lds_for(1, L.tiles1, c->max_rw, c->max_rh));
+	L.d_flows_out = d_flows_out;
+	L.d_stats = d_stats;
+	L.c = make_consts(c);
+	L.s = make_solve_consts(o);
+	if (launch_solve_independent(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "solve launch");
+	}
+	return EBO_OK;
+}
+
+int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
+{
+	CountLaunch L;
+	L.d_events = c->d_events;
+	L.d_units = c->d_units;
+	L.n_units_total = static_cast<int>(c->units.size());
+	L.n_windows = c->n_windows;
+	L.units_per_window = c->P + 1;
+	L.mode = mode;
+	L.d_aux = d_aux;
+	L.d_counts = c->d_counts;
+	L.d_image = d_image;
+	L.c = make_consts(c);
+	if (launch_count_image(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "count launch");
+	}
+	return EBO_OK;
+}
+
+int check_solver_opts(ebo_ctx* c, const ebo_solver_opts* o)
+{
+	if (!o)
+	{
+		return c->fail(EBO_ERR_ARG, "solver options are null");
+	}
+	if (o->max_num_iterations < 0 || !(o->initial_radius > 0) || o->max_consecutive_invalid < 1)
+	{
+		return c->fail(EBO_ERR_ARG, "bad solver options");
+	}
+	if (o->mode != EBO_SOLVE_GLOBAL && o->mode != EBO_SOLVE_INDEPENDENT)
+	{
+		return c->fail(EBO_ERR_ARG, "unknown solver mode");
+	}
+	return EBO_OK;
+}
+
+// EBO_SOLVE_GLOBAL: one trust-region LM per window on the host (as the
+// reference: one ceres::Problem incl. TV blocks), windows advanced in lock step
+// so that every round is ONE batched device evaluation of all data terms.
+int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary)
+{
+	const int Wn = c->n_windows;
+	const int P = c->P;
+	std::vector<HostLm> lm;
+	lm.reserve(Wn);
+	for (int w = 0; w < Wn; ++w)
+	{
+		std::vector<uint8_t> active(P);
+		for (int p = 0; p < P; ++p)
+		{
+			active[p] = (c->units[static_cast<size_t>(w) * (P + 1) + p].flags & kUnitActive) ? 1 : 0;
+		}
+		lm.emplace_back(c->npx, c->npy, active, c->prm.tv_weight, c->prm.tv_huber, *o);
+	}
+	std::vector<double> flows(static_cast<size_t>(Wn) * P * 2, 0.0);
+	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
+	for (;;)
+	{
+		bool any = false, anyJac = false;
+		for (int w = 0; w < Wn; ++w)
+		{
+			const HostLm::Request q = lm[w].request(&flows[static_cast<size_t>(w) * P * 2]);
+			if (q != HostLm::DONE)
+			{
+				any = true;
+				anyJac = anyJac || (q == HostLm::NEED_JACOBIAN);
+			}
+		}
+		if (!any)
+		{
+			break;
+		}
+		int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr);
+		if (rc)
+		{
+			return rc;
+		}
+		for (int w = 0; w < Wn; ++w)
+		{
+			lm[w].supply(&r[static_cast<size_t>(w) * P], anyJac ? &J[static_cast<size_t>(w) * P * 2] : nullptr);
+		}
+	}
+	int worst = 0;
+	for (int w = 0; w < Wn; ++w)
+	{
+		lm[w].result(flows_out + static_cast<size_t>(w) * P * 2);
+		const HostLm::Stats& s = lm[w].stats();
+		worst = std::max(worst, s.termination);
+		if (summary)
+		{
+			summary[w].iterations = s.iterations;
+			summary[w].num_evals_cost = s.evals_cost;
+			summary[w].num_evals_jac = s.evals_jac;
+			summary[w].termination = s.termination;
+			summary[w].initial_cost = s.initial_cost;
+			summary[w].final_cost = s.final_cost;
+		}
+	}
+	(void)worst;
+	return EBO_OK;
+}
+
+int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary)
+{
+	const size_t nf = static_cast<size_t>(c->n_windows) * c->P;
+	int rc = run_solve_device(c, o, c->d_flows, c->d_stats);
+	if (rc)
+	{
+		return rc;
+	}
+	std::vector<int32_t> st(nf * 4);
+	rc = c->hip(hipMemcpyAsync(flows_out, c->d_flows, nf * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H flows");
+	if (rc)
+	{
+		return rc;
+	}
+	rc = c->hip(hipMemcpyAsync(st.data(), c->d_stats, nf * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream), "D2H stats");
+	if (rc)
+	{
+		return rc;
+	}
+	rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	if (rc)
+	{
+		return rc;
+	}
+	if (summary)
+	{
+		for (int w = 0; w < c->n_windows; ++w)
+		{
+			ebo_summary s;
+			std::memset(&s, 0, sizeof(s));
+			for (int p = 0; p < c->P; ++p)
+			{
+				const int32_t* q = &st[(static_cast<size_t>(w) * c->P + p) * 4];
+				s.iterations = std::max(s.iterations, q[0]);
+				s.num_evals_cost += q[1];
+				s.num_evals_jac += q[2];
+				s.termination = std::max(s.termination, q[3]);
+			}
+			summary[w] = s;
+		}
+	}
+	return EBO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ebo_version(void)
+{
+	return "ebo_hip 0.1 (gfx950)";
+}
+
+int ebo_device_count(int* n)
+{
+	if (!n)
+	{
+		return EBO_ERR_ARG;
+	}
+	int cnt = 0;
+	if (hipGetDeviceCount(&cnt) != hipSuccess)
+	{
+		cnt = 0;
+		(void)hipGetLastError();
+	}
+	*n = cnt;
+	return EBO_OK;
+}
+
+void ebo_default_params(ebo_params* p)
+{
+	if (!p)
+	{
+		return;
+	}
+	std::memset(p, 0, sizeof(*p));
+	p->device = 0;
+	p->image_w = 240;
+	p->image_h = 180;
+	p->patch_w = 20;
+	p->patch_h = 20;
+	p->tv_weight = 1e3;
+	p->tv_huber = 10;
+	p->scale = 1e-3;
+	p->min_events = 100;
+	p->loss = EBO_LOSS_EDGE;
+	p->grad = EBO_GRAD_JET;
+	p->fd_step = 1e-6;
+	p->k.max_possible_residual = 1e3;
+	p->k.sigma_compensate = 1.0;
+	p->k.kernel_compensate = 3;
+	p->k.kernel_st = 3;
+	p->k.sigma_st = 1.5;
+	p->k.kernel_nms = 2;
+	p->max_events = 1u << 20;
+	p->max_windows = 1;
+}
+
+void ebo_default_solver(ebo_solver_opts* o)
+{
+	if (!o)
+	{
+		return;
+	}
+	o->max_num_iterations = 50;
+	o->use_nonmonotonic = 1;
+	o->function_tolerance = 1e-12;
+	o->gradient_tolerance = 1e-12;
+	o->parameter_tolerance = 1e-12;
+	o->initial_radius = 1e4;
+	o->max_radius = 1e16;
+	o->min_radius = 1e-32;
+	o->min_relative_decrease = 1e-3;
+	o->min_lm_diagonal = 1e-6;
+	o->max_lm_diagonal = 1e32;
+	o->max_consecutive_nonmonotonic = 5;
+	o->max_consecutive_invalid = 5;
+	o->jacobi_scaling = 1;
+	o->mode = EBO_SOLVE_GLOBAL;
+}
+
+const char* ebo_last_error(const ebo_ctx* ctx)
+{
+	return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int ebo_create(const ebo_params* p, ebo_ctx** out)
+{
+	if (!p || !out)
+	{
+		g_create_error = "null argument";
+		return EBO_ERR_ARG;
+	}
+	*out = nullptr;
+	if (p->image_w <= 0 || p->image_h <= 0 || p->patch_w <= 0 || p->patch_h <= 0 ||
+		p->patch_w > p->image_w || p->patch_h > p->image_h || p->image_w > kCoordMax ||
+		p->image_h > kCoordMax || p->max_events == 0 || p->max_windows <= 0 ||
+		!(p->k.sigma_compensate > 0))
+	{
+		g_create_error = "bad image/patch geometry or capacity";
+		return EBO_ERR_ARG;
+	}
+	if (p->k.kernel_compensate != 3 || p->k.kernel_st != 3 || p->k.kernel_nms != 2)
+	{
+		g_create_error = "only kernel sizes 3/3/2 (the reference's constants) are built";
+		return EBO_ERR_UNSUPPORTED;
+	}
+	if ((p->loss != EBO_LOSS_EDGE && p->loss != EBO_LOSS_VARIANCE) ||
+		(p->grad != EBO_GRAD_JET && p->grad != EBO_GRAD_CENTRAL))
+	{
+		g_create_error = "unknown loss or gradient mode";
+		return EBO_ERR_ARG;
+	}
+	if (p->max_events >= (1ull << 32))
+	{
+		g_create_error = "max_events must be below 2^32";
+		return EBO_ERR_ARG;
+	}
+	int cnt = 0;
+	if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+	{
+		(void)hipGetLastError();
+		g_create_error = "no HIP device (libebo_hip has no CPU path)";
+		return EBO_ERR_NO_DEVICE;
+	}
+	if (p->device < 0 || p->device >= cnt)
+	{
+		g_create_error = "device ordinal out of range";
+		return EBO_ERR_NO_DEVICE;
+	}
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, p->device) != hipSuccess)
+	{
+		g_create_error = "hipGetDeviceProperties failed";
+		return EBO_ERR_HIP;
+	}
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+	{
+		g_create_error = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+		return EBO_ERR_NO_DEVICE;
+	}
+	if (hipSetDevice(p->device) != hipSuccess)
+	{
+		g_create_error = "hipSetDevice failed";
+		return EBO_ERR_HIP;
+	}
+	ebo_ctx* c = new (std::nothrow) ebo_ctx();
+	if (!c)
+	{
+		g_create_error = "out of host memory";
+		return EBO_ERR_ARG;
+	}
+	c->prm = *p;
+	c->npx = p->image_w / p->patch_w;  // feature_detector.cpp:301-304
+	c->npy = p->image_h / p->patch_h;
+	c->P = c->npx * c->npy;
+	c->cap_events = p->max_events;
+	c->cap_windows = p->max_windows;
+	for (int py = 0; py < c->npy; ++py)
+	{
+		for (int px = 0; px < c->npx; ++px)
+		{
+			int x, y, w, h;
+			rect_of(c, px, py, x, y, w, h);
+			c->max_rw = std::max(c->max_rw, w);
+			c->max_rh = std::max(c->max_rh, h);
+		}
+	}
+	const size_t nf = static_cast<size_t>(c->cap_windows) * c->P;
+	const size_t npix = static_cast<size_t>(c->cap_windows) * p->image_w * p->image_h;
+	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	c->own_stream = (e == hipSuccess);
+	if (e == hipSuccess) e = hipMalloc(&c->d_events, c->cap_events * sizeof(uint64_t));
+	if (e == hipSuccess) e = hipMalloc(&c->d_units, static_cast<size_t>(c->cap_windows) * (c->P + 1) * sizeof(Unit));
+	if (e == hipSuccess) e = hipMalloc(&c->d_flows, nf * 2 * sizeof(double));
+	if (e == hipSuccess) e = hipMalloc(&c->d_out, nf * 3 * sizeof(double));
+	if (e == hipSuccess) e = hipMalloc(&c->d_stats, nf * 4 * sizeof(int32_t));
+	if (e == hipSuccess) e = hipMalloc(&c->d_counts, npix * sizeof(int32_t));
+	if (e == hipSuccess) e = hipMalloc(&c->d_image, npix * sizeof(double));
+	if (e == hipSuccess) e = hipMemset(c->d_counts, 0, npix * sizeof(int32_t));
+	if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+	if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+	if (e != hipSuccess)
+	{
+		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(e);
+		ebo_destroy(c);
+		return EBO_ERR_HIP;
+	}
+	*out = c;
+	return EBO_OK;
+}
+
+void ebo_destroy(ebo_ctx* c)
+{
+	if (!c)
+	{
+		return;
+	}
+	(void)hipSetDevice(c->prm.device);
+	if (c->stream)
+	{
+		(void)hipStreamSynchronize(c->stream);
+	}
+	hipFree(c->d_events);
+	hipFree(c->d_units);
+	hipFree(c->d_flows);
+	hipFree(c->d_out);
+	hipFree(c->d_partials);
+	hipFree(c->d_counts);
+	hipFree(c->d_image);
+	hipFree(c->d_aux);
+	hipFree(c->d_stats);
+	hipFree(c->d_scratch);
+	if (c->ev0) hipEventDestroy(c->ev0);
+	if (c->ev1) hipEventDestroy(c->ev1);
+	if (c->own_stream && c->stream)
+	{
+		hipStreamDestroy(c->stream);
+	}
+	delete c;
+}
+
+int ebo_set_stream(ebo_ctx* c, void* hip_stream)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (c->own_stream && c->stream)
+	{
+		(void)hipStreamSynchronize(c->stream);
+		hipStreamDestroy(c->stream);
+	}
+	c->stream = static_cast<hipStream_t>(hip_stream);
+	c->own_stream = false;
+	return EBO_OK;
+}
+
+int ebo_synchronize(ebo_ctx* c)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	return c->hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+}
+
+int ebo_grid(const ebo_ctx* c, int* npx, int* npy)
+{
+	if (!c || !npx || !npy)
+	{
+		return EBO_ERR_ARG;
+	}
+	*npx = c->npx;
+	*npy = c->npy;
+	return EBO_OK;
+}
+
+int ebo_patch_rect(const ebo_ctx* c, int px, int py, int* x, int* y, int* w, int* h)
+{
+	if (!c || !x || !y || !w || !h || px < 0 || py < 0 || px >= c->npx || py >= c->npy)
+	{
+		return EBO_ERR_ARG;
+	}
+	rect_of(c, px, py, *x, *y, *w, *h);
+	return EBO_OK;
+}
+
+int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_windows)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!offsets || n_windows <= 0 || (!ev && offsets[n_windows] > offsets[0]))
+	{
+		return c->fail(EBO_ERR_ARG, "null events/offsets or no window");
+	}
+	if (n_windows > c->cap_windows)
+	{
+		return c->fail(EBO_ERR_ARG, "more windows than max_windows");
+	}
+	const size_t total = offsets[n_windows] - offsets[0];
+	if (total > c->cap_events)
+	{
+		return c->fail(EBO_ERR_ARG, "more events than max_events");
+	}
+	const int P = c->P;
+	const int pw = c->prm.patch_w, ph = c->prm.patch_h;
+	std::vector<Unit> units(static_cast<size_t>(n_windows) * (P + 1));
+	std::vector<int64_t> utref(units.size(), 0);
+	std::vector<WindowInfo> wins(n_windows);
+	c->h_packed.resize(total);
+	std::vector<uint32_t> cnt(P + 1), cur(P + 1);
+	std::vector<int64_t> first(P + 1), last(P + 1);
+	size_t base = 0;
+	for (int w = 0; w < n_windows; ++w)
+	{
+		if (offsets[w + 1] < offsets[w])
+		{
+			return c->fail(EBO_ERR_ARG, "offsets must be non-decreasing");
+		}
+		const ebo_event* we = ev + offsets[w];
+		const size_t n = offsets[w + 1] - offsets[w];
+		int64_t tw = 0;
+		if (n > 0 && !mid_timestamp(we[0].t_us, we[n - 1].t_us, tw))
+		{
+			return c->fail(EBO_ERR_RANGE, "window mid-time outside int32 microseconds (undefined in the reference)");
+		}
+		wins[w].t_ref = tw;
+		wins[w].n_events = n;
+		std::fill(cnt.begin(), cnt.end(), 0u);
+		// patch of an event == the grid rect that contains it (feature_detector.cpp:332-355)
+		auto bucket_of = [&](const ebo_event& e) -> int {
+			if (e.x < 0 || e.x >= c->prm.image_w || e.y < 0 || e.y >= c->prm.image_h)
+			{
+				return P;
+			}
+			const int bx = std::min(e.x / pw, c->npx - 1);
+			const int by = std::min(e.y / ph, c->npy - 1);
+			return by * c->npx + bx;
+		};
+		for (size_t i = 0; i < n; ++i)
+		{
+			if (we[i].x < kCoordMin || we[i].x > kCoordMax || we[i].y < kCoordMin || we[i].y > kCoordMax)
+			{
+				return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
+			}
+			const int b = bucket_of(we[i]);
+			if (cnt[b] == 0)
+			{
+				first[b] = we[i].t_us;
+			}
+			last[b] = we[i].t_us;
+			cnt[b]++;
+		}
+		size_t off = base;
+		for (int b = 0; b <= P; ++b)
+		{
+			Unit& u = units[static_cast<size_t>(w) * (P + 1) + b];
+			u.ev_off = static_cast<uint32_t>(off);
+			u.n_ev = cnt[b];
+			u.flags = 0;
+			u.flow_idx = static_cast<uint32_t>(static_cast<size_t>(w) * P + std::min(b, P - 1));
+			int64_t tu = tw;
+			if (b < P)
+			{
+				int x, y, rw, rh;
+				rect_of(c, b % c->npx, b / c->npx, x, y, rw, rh);
+				u.rx = static_cast<int16_t>(x);
+				u.ry = static_cast<int16_t>(y);
+				u.rw = static_cast<int16_t>(rw);
+				u.rh = static_cast<int16_t>(rh);
+				if (cnt[b] > 0 && !mid_timestamp(first[b], last[b], tu))
+				{
+					return c->fail(EBO_ERR_RANGE, "patch mid-time outside int32 microseconds");
+				}
+				if (cnt[b] > c->prm.min_events)  // feature_detector.cpp:357, strictly greater
+				{
+					u.flags |= kUnitActive;
+				}
+			}
+			else
+			{
+				u.rx = u.ry = 0;
+				u.rw = u.rh = 1;
+				u.flags |= kUnitStray;
+			}
+			utref[static_cast<size_t>(w) * (P + 1) + b] = tu;
+			const int64_t dwin = tw - tu;
+			if (dwin < INT32_MIN || dwin > INT32_MAX)
+			{
+				return c->fail(EBO_ERR_RANGE, "time span exceeds int32 microseconds");
+			}
+			u.dt_win = static_cast<int32_t>(dwin);
+			cur[b] = static_cast<uint32_t>(off - base);
+			off += cnt[b];
+		}
+		for (size_t i = 0; i < n; ++i)
+		{
+			const int b = bucket_of(we[i]);
+			const int64_t tu = utref[static_cast<size_t>(w) * (P + 1) + b];
+			const int64_t dt = tu - we[i].t_us;
+			const int64_t dtw = tw - we[i].t_us;
+			if (dt < INT32_MIN || dt > INT32_MAX || dtw < INT32_MIN || dtw > INT32_MAX)
+			{
+				return c->fail(EBO_ERR_RANGE, "event time further than 2^31 us from the reference time");
+			}
+			const uint64_t rec = static_cast<uint64_t>(pack_lo(we[i].x, we[i].y, we[i].sign > 0)) |
+								 (static_cast<uint64_t>(static_cast<uint32_t>(static_cast<int32_t>(dt))) << 32);
+			c->h_packed[base + cur[b]++] = rec;
+		}
+		base += n;
+	}
+	(void)hipSetDevice(c->prm.device);
+	int rc = EBO_OK;
+	if (total > 0)
+	{
+		rc = c->hip(hipMemcpyAsync(c->d_events, c->h_packed.data(), total * sizeof(uint64_t),
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D events");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(Unit),
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D units");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipStreamSynchronize(c->stream), "sync after upload");
+	}
+	if (rc != EBO_OK)
+	{
+		c->n_windows = 0;
+		return rc;
+	}
+	c->units.swap(units);
+	c->unit_tref.swap(utref);
+	c->windows.swap(wins);
+	c->n_windows = n_windows;
+	return EBO_OK;
+}
+
+int ebo_set_window(ebo_ctx* c, const ebo_event* ev, size_t n)
+{
+	const size_t offsets[2] = {0, n};
+	return ebo_set_windows(c, ev, offsets, 1);
+}
+
+int ebo_num_windows(const ebo_ctx* c, int* n)
+{
+	if (!c || !n)
+	{
+		return EBO_ERR_ARG;
+	}
+	*n = c->n_windows;
+	return EBO_OK;
+}
+
+int ebo_window_info(const ebo_ctx* c, int window, int64_t* t_ref_us, uint64_t* n_events)
+{
+	if (!c || window < 0 || window >= c->n_windows)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (t_ref_us) *t_ref_us = c->windows[window].t_ref;
+	if (n_events) *n_events = c->windows[window].n_events;
+	return EBO_OK;
+}
+
+int ebo_patch_info(const ebo_ctx* c, int window, int patch, int32_t* n_events, int32_t* active,
+				   int64_t* t_ref_us)
+{
+	if (!c || window < 0 || window >= c->n_windows || patch < 0 || patch >= c->P)
+	{
+		return EBO_ERR_ARG;
+	}
+	const size_t i = static_cast<size_t>(window) * (c->P + 1) + patch;
+	if (n_events) *n_events = static_cast<int32_t>(c->units[i].n_ev);
+	if (active) *active = (c->units[i].flags & kUnitActive) ? 1 : 0;
+	if (t_ref_us) *t_ref_us = c->unit_tref[i];
+	return EBO_OK;
+}
+
+int ebo_eval(ebo_ctx* c, const double* flows, double* r, double* jac)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!flows || !r)
+	{
+		return c->fail(EBO_ERR_ARG, "null flows or residual pointer");
+	}
+	if (c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	(void)hipSetDevice(c->prm.device);
+	return eval_host(c, flows, r, jac);
+}
+
+int ebo_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!d_flows || !d_out)
+	{
+		return c->fail(EBO_ERR_ARG, "null device pointer");
+	}
+	return run_eval_device(c, d_flows, want_jac, d_out);
+}
+
+int ebo_contrast_image(ebo_ctx* c, int window, int patch, const double* flow, int channels,
+					   double* image)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!flow || !image || (channels != 1 && channels != 3) || window < 0 ||
+		window >= c->n_windows || patch < 0 || patch >= c->P)
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to ebo_contrast_image");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t ui = static_cast<size_t>(window) * (c->P + 1) + patch;
+	const Unit& u = c->units[ui];
+	const size_t npx = static_cast<size_t>(9) * u.rw * u.rh;
+	int rc = ensure_aux(c, npx * channels * sizeof(double) + 2 * sizeof(double));
+	if (rc)
+	{
+		return rc;
+	}
+	double* d_img = static_cast<double*>(c->d_aux);
+	double* d_flow = d_img + npx * channels;
+	rc = c->hip(hipMemcpyAsync(d_flow, flow, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream), "H2D flow");
+	if (rc)
+	{
+		return rc;
+	}
+	EvalLaunch L;
+	std::memset(&L, 0, sizeof(L));
+	L.d_events = c->d_events;
+	L.d_units = c->d_units;
+	L.d_flows = d_flow;
+	L.channels = channels;
+	L.tiles = min_tiles(channels, u.rw, u.rh, kLdsBudget);
+	if (L.tiles < 0)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "patch too wide for LDS row tiling");
+	}
+	L.block = 256;
+	L.lds_bytes = lds_for(channels, L.tiles, u.rw, u.rh);
+	L.c = make_consts(c);
+	if (launch_dump_image(L, static_cast<int>(ui), d_img, c->stream))
+	{
+		return c->hip(hipGetLastError(), "dump launch");
+	}
+	rc = c->hip(hipMemcpyAsync(image, d_img, npx * channels * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H image");
+	if (rc)
+	{
+		return rc;
+	}
+	return c->hip(hipStreamSynchronize(c->stream), "sync");
+}
+
+int ebo_solve(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!flows_out)
+	{
+		return c->fail(EBO_ERR_ARG, "null flows_out");
+	}
+	int rc = check_solver_opts(c, o);
+	if (rc)
+	{
+		return rc;
+	}
+	if (c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	(void)hipSetDevice(c->prm.device);
+	if (o->mode == EBO_SOLVE_INDEPENDENT)
+	{
+		return solve_independent_host(c, o, flows_out, summary);
+	}
+	return solve_global(c, o, flows_out, summary);
+}
+
+int ebo_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, int32_t* d_stats)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!d_flows_out)
+	{
+		return c->fail(EBO_ERR_ARG, "null device pointer");
+	}
+	int rc = check_solver_opts(c, o);
+	if (rc)
+	{
+		return rc;
+	}
+	if (o->mode != EBO_SOLVE_INDEPENDENT)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "ebo_solve_device runs EBO_SOLVE_INDEPENDENT only");
+	}
+	return run_solve_device(c, o, d_flows_out, d_stats);
+}
+
+int ebo_count_image(ebo_ctx* c, int mode, const void* aux, double* image)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!image || mode < 0 || mode > 2 || (mode != EBO_COUNT_INTEGRATED && !aux))
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image");
+	}
+	if (c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t npix = static_cast<size_t>(c->n_windows) * c->prm.image_w * c->prm.image_h;
+	const void* d_aux = nullptr;
+	int rc = EBO_OK;
+	if (mode == EBO_COUNT_WARPED)
+	{
+		const size_t bytes = static_cast<size_t>(c->n_windows) * c->P * 2 * sizeof(double);
+		rc = c->hip(hipMemcpyAsync(c->d_flows, aux, bytes, hipMemcpyHostToDevice, c->stream), "H2D flows");
+		d_aux = c->d_flows;
+	}
+	else if (mode == EBO_COUNT_FIELD)
+	{
+		const size_t bytes = npix * 2 * sizeof(float);
+		rc = ensure_aux(c, bytes);
+		if (rc == EBO_OK)
+		{
+			rc = c->hip(hipMemcpyAsync(c->d_aux, aux, bytes, hipMemcpyHostToDevice, c->stream), "H2D field");
+		}
+		d_aux = c->d_aux;
+	}
+	if (rc)
+	{
+		return rc;
+	}
+	rc = count_device(c, mode, d_aux, c->d_image);
+	if (rc)
+	{
+		return rc;
+	}
+	rc = c->hip(hipMemcpyAsync(image, c->d_image, npix * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H image");
+	if (rc)
+	{
+		return rc;
+	}
+	return c->hip(hipStreamSynchronize(c->stream), "sync");
+}
+
+int ebo_count_image_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!d_image || mode < 0 || mode > 2 || (mode != EBO_COUNT_INTEGRATED && !d_aux))
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image_device");
+	}
+	if (c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	return count_device(c, mode, d_aux, d_image);
+}
+
+int ebo_compensate_events_contrast(ebo_ctx* c, const ebo_event* ev, size_t n,
+								   const ebo_solver_opts* o, double* flows_out,
+								   double* image_out, ebo_summary* summary)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!ev || n == 0 || !flows_out)
+	{
+		return c->fail(EBO_ERR_ARG, "empty window or null output");
+	}
+	int rc = ebo_set_window(c, ev, n);
+	if (rc)
+	{
+		return rc;
+	}
+	rc = ebo_solve(c, o, flows_out, summary);
+	if (rc)
+	{
+		return rc;
+	}
+	if (image_out)
+	{
+		rc = ebo_count_image(c, EBO_COUNT_WARPED, flows_out, image_out);
+	}
+	return rc;
+}
+
+static int patch_integrate_common(ebo_ctx* c, const ebo_event* ev, const size_t* offsets,
+								  int n_patches, const double* rects, const double* traj,
+								  const int64_t* mid_time, const size_t* nabla_offsets,
+								  double* nabla, int64_t* current_ts, int64_t* time_last_update,
+								  int32_t* updated)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!ev || !offsets || n_patches <= 0 || !rects || !nabla_offsets || !nabla)
+	{
+		return c->fail(EBO_ERR_ARG, "null argument to patch integrate");
+	}
+	const bool mc = traj != nullptr;
+	if (mc && (!mid_time || !updated))
+	{
+		return c->fail(EBO_ERR_ARG, "null mid_time/updated");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t e0 = offsets[0];
+	const size_t total = offsets[n_patches] - e0;
+	if (total >= (1ull << 32))
+	{
+		return c->fail(EBO_ERR_ARG, "too many events");
+	}
+	std::vector<uint64_t> packed(total);
+	std::vector<uint32_t> off32(n_patches + 1);
+	std::vector<double> tr(mc ? static_cast<size_t>(n_patches) * 4 : 0);
+	std::vector<uint64_t> noff(n_patches);
+	size_t nablaEnd = 0;
+	for (int p = 0; p < n_patches; ++p)
+	{
+		const size_t a = offsets[p], b = offsets[p + 1];
+		if (b < a)
+		{
+			return c->fail(EBO_ERR_ARG, "offsets must be non-decreasing");
+		}
+		off32[p] = static_cast<uint32_t>(a - e0);
+		const double rw = rects[4 * p + 2], rh = rects[4 * p + 3];
+		const int cols = static_cast<int>(rw), rows = static_cast<int>(rh);
+		if (cols <= 0 || rows <= 0 || static_cast<size_t>(cols) * rows > 16384)
+		{
+			return c->fail(EBO_ERR_UNSUPPORTED, "patch image must have 1..16384 pixels");
+		}
+		noff[p] = nabla_offsets[p];
+		nablaEnd = std::max(nablaEnd, nabla_offsets[p] + static_cast<size_t>(cols) * rows);
+		int64_t tref = 0;
+		bool pass = true;
+		if (mc)
+		{
+			// patch.cpp:94-100
+			const int64_t preT = static_cast<int64_t>(traj[6 * p + 2]);
+			const int64_t lastT = static_cast<int64_t>(traj[6 * p + 5]);
+			const double halfD = static_cast<double>(lastT - preT) * 0.5;
+			if (!(halfD > -2147483648.0 && halfD < 2147483648.0))
+			{
+				return c->fail(EBO_ERR_RANGE, "trajectory time step outside int32 microseconds");
+			}
+			const int64_t half = static_cast<int64_t>(static_cast<int32_t>(halfD));
+			tref = mid_time[p];
+			pass = (b > a) && (lastT + half >= tref) && (preT < tref);
+			tr[4 * p + 0] = traj[6 * p + 3] - traj[6 * p + 0];
+			tr[4 * p + 1] = traj[6 * p + 4] - traj[6 * p + 1];
+			tr[4 * p + 2] = static_cast<double>(lastT - preT);
+			tr[4 * p + 3] = pass ? 1.0 : 0.0;
+			updated[p] = pass ? 1 : 0;
+		}
+		else if (b > a)
+		{
+			// patch.cpp:78-83
+			int64_t mid;
+			if (!mid_timestamp(ev[a].t_us, ev[b - 1].t_us, mid))
+			{
+				return c->fail(EBO_ERR_RANGE, "patch mid-time outside int32 microseconds");
+			}
+			if (current_ts) current_ts[p] = mid;
+			if (time_last_update)
+			{
+				time_last_update[p] = static_cast<int64_t>(static_cast<int32_t>(ev[b - 1].t_us));
+			}
+		}
+		for (size_t i = a; i < b; ++i)
+		{
+			if (ev[i].x < kCoordMin || ev[i].x > kCoordMax || ev[i].y < kCoordMin || ev[i].y > kCoordMax)
+			{
+				return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
+			}
+			const int64_t dt = mc ? (tref - ev[i].t_us) : 0;
+			if (dt < INT32_MIN || dt > INT32_MAX)
+			{
+				return c->fail(EBO_ERR_RANGE, "event time further than 2^31 us from mid time");
+			}
+			packed[i - e0] = static_cast<uint64_t>(pack_lo(ev[i].x, ev[i].y, ev[i].sign > 0)) |
+							 (static_cast<uint64_t>(static_cast<uint32_t>(static_cast<int32_t>(dt))) << 32);
+		}
+	}
+	off32[n_patches] = static_cast<uint32_t>(total);
+	// staging layout: events | offsets | rects | traj | nabla offsets | nabla
+	auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+	const size_t bEv = align(total * 8), bOff = align(off32.size() * 4), bRect = align(static_cast<size_t>(n_patches) * 32);
+	const size_t bTraj = align(tr.size() * 8), bNoff = align(noff.size() * 8), bNabla = align(nablaEnd * 8);
+	int rc = ensure_scratch(c, bEv + bOff + bRect + bTraj + bNoff + bNabla);
+	if (rc)
+	{
+		return rc;
+	}
+	char* base = static_cast<char*>(c->d_scratch);
+	char* dEv = base;
+	char* dOff = dEv + bEv;
+	char* dRect = dOff + bOff;
+	char* dTraj = dRect + bRect;
+	char* dNoff = dTraj + bTraj;
+	char* dNabla = dNoff + bNoff;
+	hipError_t e = hipSuccess;
+	if (total) e = hipMemcpyAsync(dEv, packed.data(), total * 8, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dOff, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dRect, rects, static_cast<size_t>(n_patches) * 32, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && mc) e = hipMemcpyAsync(dTraj, tr.data(), tr.size() * 8, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dNoff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, c->stream);
+	// R6 leaves images of patches that fail the time test untouched: start from the caller's data
+	if (e == hipSuccess && mc) e = hipMemcpyAsync(dNabla, nabla, nablaEnd * 8, hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D patch data");
+	}
+	PatchIntLaunch L;
+	L.d_events = reinterpret_cast<const uint64_t*>(dEv);
+	L.d_offsets = reinterpret_cast<const uint32_t*>(dOff);
+	L.d_rects = reinterpret_cast<const double*>(dRect);
+	L.d_traj = mc ? reinterpret_cast<const double*>(dTraj) : nullptr;
+	L.d_nabla_off = reinterpret_cast<const uint64_t*>(dNoff);
+	L.d_nabla = reinterpret_cast<double*>(dNabla);
+	L.n_patches = n_patches;
+	if (launch_patch_integrate(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "patch integrate launch");
+	}
+	rc = c->hip(hipMemcpyAsync(nabla, dNabla, nablaEnd * 8, hipMemcpyDeviceToHost, c->stream), "D2H nabla");
+	if (rc)
+	{
+		return rc;
+	}
+	return c->hip(hipStreamSynchronize(c->stream), "sync");
+}
+
+int ebo_patch_integrate(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_patches,
+						const double* rects, const size_t* nabla_offsets, double* nabla,
+						int64_t* current_ts, int64_t* time_last_update)
+{
+	return patch_integrate_common(c, ev, offsets, n_patches, rects, nullptr, nullptr,
+								  nabla_offsets, nabla, current_ts, time_last_update, nullptr);
+}
+
+int ebo_patch_integrate_mc(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_patches,
+						   const double* rects, const double* traj, const int64_t* mid_time,
+						   const size_t* nabla_offsets, double* nabla, int32_t* updated)
+{
+	if (c && !traj)
+	{
+		return c->fail(EBO_ERR_ARG, "null trajectory");
+	}
+	return patch_integrate_common(c, ev, offsets, n_patches, rects, traj, mid_time, nabla_offsets,
+								  nabla, nullptr, nullptr, updated);
+}
+
+int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end)
+{
+	if (n_units < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end)
+	{
+		return EBO_ERR_ARG;
+	}
+	const int base = n_units / world, rem = n_units % world;
+	*begin = rank * base + std::min(rank, rem);
+	*end = *begin + base + (rank < rem ? 1 : 0);
+	return EBO_OK;
+}
+
+int ebo_timer_begin(ebo_ctx* c)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	return c->hip(hipEventRecord(c->ev0, c->stream), "hipEventRecord");
+}
+
+int ebo_timer_end(ebo_ctx* c, float* ms)
+{
+	if (!c || !ms)
+	{
+		return EBO_ERR_ARG;
+	}
+	int rc = c->hip(hipEventRecord(c->ev1, c->stream), "hipEventRecord");
+	if (rc) return rc;
+	rc = c->hip(hipEventSynchronize(c->ev1), "hipEventSynchronize");
+	if (rc) return rc;
+	return c->hip(hipEventElapsedTime(ms, c->ev0, c->ev1), "hipEventElapsedTime");
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// ebo_internal.h — types shared by the host side (ebo_api.cpp) and the device
+// side (ebo_kernels.hip) of libebo_hip.so.  Not part of the ABI.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ebo
+{
+// One event in HBM: 8 bytes (the algorithmic bytes per
+// event-evaluation).
+//   lo bits  0..14  x   (15-bit two's complement)
+//      bit   15     polarity (1 = POSITIVE)
+//      bits 16..30  y   (15-bit two's complement)
+//      bit   31     unused
+//   hi             dt = t_ref(unit) - t_event   in microseconds (int32)
+// Events are stored bucketed by unit (window, patch), time order kept inside a
+// unit, so that one workgroup streams one contiguous, coalesced range.
+static const int kCoordMin = -16384;
+static const int kCoordMax = 16383;
+
+inline uint32_t pack_lo(int x, int y, int positive)
+{
+	return (static_cast<uint32_t>(x) & 0x7FFFu) |
+		   (static_cast<uint32_t>(positive ? 1 : 0) << 15) |
+		   ((static_cast<uint32_t>(y) & 0x7FFFu) << 16);
+}
+
+// A unit = one patch of one window (a contrastFunctor instance), or the stray
+// bucket of a window (events outside the sensor; flag bit 1).
+struct Unit
+{
+	uint32_t ev_off;   // first packed event
+	uint32_t n_ev;     // number of events
+	int16_t rx, ry;    // patch rect (cv::Rect2i)
+	int16_t rw, rh;
+	int32_t dt_win;    // t_ref(window) - t_ref(unit): dt_window = dt + dt_win
+	uint32_t flags;    // bit0: active (n_ev > min_events); bit1: stray bucket
+	uint32_t flow_idx; // index of this unit's flow in the [Wn][P] arrays
+};
+static_assert(sizeof(Unit) == 28, "Unit layout");
+
+static const uint32_t kUnitActive = 1u;
+static const uint32_t kUnitStray = 2u;
+
+// Constants of one evaluation, passed by value to kernels.
+struct EvalConsts
+{
+	double scale;         // compensateScale
+	double max_res;       // maxPossibleResidual_
+	double norm;          // 1 / (2 pi sigma^2)
+	double hs;            // -0.5 / sigma^2
+	double inv_sigsq;     // 1 / sigma^2
+	int32_t image_w, image_h;
+	int32_t patch_w, patch_h;
+	int32_t npx, npy;
+};
+
+// ceres-style solver options for the device solver (mirror of ebo_solver_opts).
+struct SolveConsts
+{
+	int32_t max_num_iterations;
+	int32_t max_nonmono;  // 0 when use_nonmonotonic is off
+	int32_t max_invalid;
+	int32_t jacobi_scaling;
+	double function_tolerance, gradient_tolerance, parameter_tolerance;
+	double initial_radius, max_radius, min_radius;
+	double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+};
+
+// Per-block partial sums of the variance objective: S1, S2, n, D1[2], D2[2], pad.
+static const int kPartialStride = 8;
+
+// ---- launch wrappers implemented in ebo_kernels.hip (hipStream_t as void*) ----
+struct EvalLaunch
+{
+	const uint64_t* d_events;
+	const Unit* d_units;
+	int n_units;           // patch units only (strays excluded)
+	const double* d_flows; // [flow sets][n_flow][2]
+	int n_flow;            // flows per flow set (= Wn * P)
+	int flow_sets;         // 1, or 5 for central differences
+	int channels;          // 1 or 3
+	int tiles;             // row tiles per unit
+	int block;             // threads per workgroup
+	size_t lds_bytes;
+	double* d_partials;    // [flow sets][n_units][tiles][kPartialStride]
+	double* d_out;         // [n_flow][3]
+	double fd_step;        // > 0: combine as central differences
+	EvalConsts c;
+};
+int launch_eval_variance(const EvalLaunch& L, void* stream);
+int launch_dump_image(const EvalLaunch& L, int unit, double* d_image, void* stream);
+
+struct SolveLaunch
+{
+	const uint64_t* d_events;
+	const Unit* d_units;
+	int n_units;
+	int tiles3, tiles1;  // sequential row tiles for the 3- and 1-channel image
+	int block;
+	size_t lds_bytes;
+	double* d_flows_out; // [n_flow][2]
+	int32_t* d_stats;    // [n_flow][4] or null
+	EvalConsts c;
+	SolveConsts s;
+};
+int launch_solve_independent(const SolveLaunch& L, void* stream);
+
+struct CountLaunch
+{
+	const uint64_t* d_events;
+	const Unit* d_units;
+	int n_units_total;    // patch units + stray units
+	int n_windows;
+	int units_per_window; // P + 1
+	int mode;             // EBO_COUNT_*
+	const void* d_aux;    // flows f64 [Wn][P][2] or field f32 [Wn][H][W][2]
+	int32_t* d_counts;    // [Wn][H][W] scratch, zero on entry, zero on exit
+	double* d_image;      // [Wn][H][W]
+	EvalConsts c;
+};
+int launch_count_image(const CountLaunch& L, void* stream);
+
+struct PatchIntLaunch
+{
+	const uint64_t* d_events;  // packed, dt = mid_time - t
+	const uint32_t* d_offsets; // [n+1]
+	const double* d_rects;     // [n][4]
+	const double* d_traj;      // [n][4] = dirX, dirY, tDif, pass(0/1); null for R5
+	const uint64_t* d_nabla_off; // [n]
+	double* d_nabla;
+	int n_patches;
+};
+int launch_patch_integrate(const PatchIntLaunch& L, void* stream);
+
+}  // namespace ebo

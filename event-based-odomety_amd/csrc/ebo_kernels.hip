@@ -1,0 +1,929 @@
+// ebo_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, CDNA4).
+//
+// Hot path of nurlanov-zh/event-based-odomety's motion compensation:
+//   warp each event by its patch's candidate flow over its dt      (contrast_functor.h:47-54)
+//   7x7 Gaussian splat into the 3W x 3H image of warped events     (contrast_functor.h:56-86)
+//   variance objective + forward-mode Jacobian                     (contrast_functor.h:101-150)
+//   per-patch Levenberg-Marquardt on the device                    (feature_detector.cpp:401-414, TV = 0)
+//   integer event-count images                                     (feature_detector.cpp:433-482, :270-295; patch.cpp:65-130)
+//
+// Design (DESIGN.md has the numbers):
+//   * events are 8-byte packed records, bucketed by patch, streamed from HBM in
+//     coalesced 512-B wave reads; one lane owns one event.
+//   * the image of warped events lives only in LDS (planar f64 channels: value,
+//     d/dm0, d/dm1); taps are scatter-added with native ds_add_f64; nothing but
+//     7 partial sums per workgroup ever goes back to HBM.
+//   * reductions: wave64 shuffles, then one LDS hop across waves, fixed order.
+//   * no MFMA: this is scatter + reduce, not a contraction.
+// Built with -ffp-contract=off: the warped coordinate must round exactly like
+// the CPU path (one rounding per operation) because it is truncated to a bin.
+#include <hip/hip_runtime.h>
+
+#include "ebo_internal.h"
+
+namespace ebo
+{
+namespace
+{
+constexpr int kMaxWaves = 16;
+
+__device__ __forceinline__ void unpack(uint64_t rec, int& x, int& y, int& pos, int& dt)
+{
+	const uint32_t lo = static_cast<uint32_t>(rec);
+	dt = static_cast<int>(static_cast<uint32_t>(rec >> 32));
+	x = static_cast<int>(lo << 17) >> 17;
+	y = static_cast<int>(lo << 1) >> 17;
+	pos = (lo >> 15) & 1u;
+}
+
+__device__ __forceinline__ bool convertible(double c)
+{
+	return fabs(c) < 1073741824.0;  // int(double) is defined; same guard as the CPU path
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		v += __shfl_down(v, off, 64);
+	}
+	return v;
+}
+
+// Sums NV per-thread values over the workgroup; every thread gets the totals.
+// Order is fixed (lanes by shuffle tree, then waves 0..nw-1) => deterministic.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+	for (int k = 0; k < NV; ++k)
+	{
+		v[k] = wave_sum(v[k]);
+	}
+	__syncthreads();  // red may still be read by a previous call
+	if (lane == 0)
+	{
+#pragma unroll
+		for (int k = 0; k < NV; ++k)
+		{
+			red[wave * 8 + k] = v[k];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < NV; ++k)
+	{
+		double s = red[k];
+		for (int w = 1; w < nw; ++w)
+		{
+			s += red[w * 8 + k];
+		}
+		v[k] = s;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Warp + 7x7 Gaussian splat of one unit's events into rows [r0, r0+rows) of its
+// 3W x 3H image (contrast_functor.h:38-88).  C = 1: value only (the T=double
+// instantiation); C = 3: value, d/dm0, d/dm1 (the Jet<double,2> instantiation).
+//   c = p + (t_ref - t) * scale * m;  b = int(c)  (truncation)
+//   tap (i,j): w = N * exp(hs * ((b.x+i-c.x)^2 + (b.y+j-c.y)^2))
+//   dw/dm0 = w * (b.x+i-c.x) * tau / sigma^2,   dw/dm1 likewise in y
+// The Gaussian is evaluated as a product of two 1-D factors (7+7 exps instead
+// of 49): same real number, last-bit differences only.
+// ---------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void splat_rows(const uint64_t* __restrict__ ev, uint32_t nEv,
+											int rx, int ry, int rw, int rh, int r0, int rows,
+											double m0, double m1, const EvalConsts& c,
+											double* __restrict__ img, int plane)
+{
+	const int W3 = 3 * rw;
+	for (uint32_t e = threadIdx.x; e < nEv; e += blockDim.x)
+	{
+		int x, y, pos, dt;
+		unpack(ev[e], x, y, pos, dt);
+		const double tau = static_cast<double>(dt) * c.scale;
+		const double cx = static_cast<double>(x) + tau * m0;
+		const double cy = static_cast<double>(y) + tau * m1;
+		if (!convertible(cx) || !convertible(cy))
+		{
+			continue;
+		}
+		const int bx = static_cast<int>(cx);
+		const int by = static_cast<int>(cy);
+		const int pxc = bx - rx + rw;       // column of tap i = 0
+		const int pyc = by - ry + rh - r0;  // tile-local row of tap j = 0
+		if (pxc + 3 < 0 || pxc - 3 >= W3 || pyc + 3 < 0 || pyc - 3 >= rows)
+		{
+			continue;
+		}
+		const double fx = cx - static_cast<double>(bx);  // exact
+		const double fy = cy - static_cast<double>(by);
+		const double g = tau * c.inv_sigsq;
+
+		double wx[7], wy[7], ax[7], ay[7];
+#pragma unroll
+		for (int k = 0; k < 7; ++k)
+		{
+			const double dx = static_cast<double>(k - 3) - fx;  // == (b.x+i) - c.x
+			const double dy = static_cast<double>(k - 3) - fy;
+			wx[k] = c.norm * exp(c.hs * (dx * dx));
+			wy[k] = exp(c.hs * (dy * dy));
+			if (C == 3)
+			{
+				ax[k] = wx[k] * (g * dx);
+				ay[k] = wy[k] * (g * dy);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 7; ++j)
+		{
+			const int row = pyc + j - 3;
+			if (row < 0 || row >= rows)
+			{
+				continue;
+			}
+			double* rowp = img + row * W3 + (pxc - 3);
+#pragma unroll
+			for (int i = 0; i < 7; ++i)
+			{
+				const int col = pxc + i - 3;
+				if (col < 0 || col >= W3)
+				{
+					continue;
+				}
+				atomicAdd(rowp + i, wx[i] * wy[j]);
+				if (C == 3)
+				{
+					atomicAdd(rowp + plane + i, ax[i] * wy[j]);
+					atomicAdd(rowp + 2 * plane + i, wx[i] * ay[j]);
+				}
+			}
+		}
+	}
+}
+
+// Sums over the pixels with I > 0 of one tile (contrast_functor.h:111-121,
+// :129-139 folded into one pass): S1 = sum I, S2 = sum I^2, n, D1k = sum dIk,
+// D2k = sum I dIk.
+template <int C>
+__device__ __forceinline__ void tile_sums(const double* __restrict__ img, int plane,
+										   double* red, double (&out)[7])
+{
+	double v[7] = {0, 0, 0, 0, 0, 0, 0};
+	for (int p = threadIdx.x; p < plane; p += blockDim.x)
+	{
+		const double I = img[p];
+		if (I > 0.0)
+		{
+			v[0] += I;
+			v[1] += I * I;
+			v[2] += 1.0;
+			if (C == 3)
+			{
+				const double a = img[plane + p];
+				const double b = img[2 * plane + p];
+				v[3] += a;
+				v[4] += b;
+				v[5] += I * a;
+				v[6] += I * b;
+			}
+		}
+	}
+	block_sum<7>(v, red);
+#pragma unroll
+	for (int k = 0; k < 7; ++k)
+	{
+		out[k] = v[k];
+	}
+}
+
+// contrast_functor.h:122-149 from the sums.  counterNonZero starts at 1 (:110).
+//   mean = S1/cnt;  var = sum_{I>0}(I-mean)^2 / cnt = (S2 - 2 mean S1 + n mean^2)/cnt
+//   r = maxRes - var, or the out-of-window penalty maxRes (1 + m0^2 + m1^2) if mean <= 0.
+__device__ __forceinline__ void variance_from_sums(const double* S, bool wantJac, double m0,
+													double m1, double maxRes, double& r,
+													double& j0, double& j1)
+{
+	const double n = S[2];
+	const double cntInv = 1.0 / (n + 1.0);
+	const double mean = S[0] * cntInv;
+	if (mean > 0.0)
+	{
+		const double var = (S[1] - 2.0 * mean * S[0] + n * mean * mean) * cntInv;
+		r = maxRes - var;
+		if (wantJac)
+		{
+			const double dm0 = S[3] * cntInv;
+			const double dm1 = S[4] * cntInv;
+			j0 = -(2.0 * (S[5] - mean * S[3] - dm0 * S[0] + n * mean * dm0) * cntInv);
+			j1 = -(2.0 * (S[6] - mean * S[4] - dm1 * S[0] + n * mean * dm1) * cntInv);
+		}
+	}
+	else
+	{
+		r = maxRes * (1.0 + m0 * m0 + m1 * m1);
+		j0 = maxRes * (m0 + m0);
+		j1 = maxRes * (m1 + m1);
+	}
+}
+
+__device__ __forceinline__ void fd_offset(int set, double h, double& m0, double& m1)
+{
+	if (set == 1) m0 += h;
+	if (set == 2) m0 -= h;
+	if (set == 3) m1 += h;
+	if (set == 4) m1 -= h;
+}
+
+// ---------------------------------------------------------------------------
+// Batched objective evaluation (R1): workgroup = (flow set, unit, row tile).
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ void k_eval_variance(const uint64_t* __restrict__ events,
+								const Unit* __restrict__ units, const double* __restrict__ flows,
+								int tiles, double fdStep, double* __restrict__ partials,
+								double* __restrict__ out, EvalConsts c)
+{
+	extern __shared__ double lds[];
+	const int unit = blockIdx.x / tiles;
+	const int tile = blockIdx.x - unit * tiles;
+	const int set = blockIdx.y;
+	const Unit u = units[unit];
+	double* part = partials + ((static_cast<size_t>(set) * gridDim.x) + blockIdx.x) * kPartialStride;
+	const bool fused = (tiles == 1 && gridDim.y == 1);
+	if (!(u.flags & kUnitActive))
+	{
+		if (threadIdx.x < 7)
+		{
+			part[threadIdx.x] = 0.0;
+		}
+		if (fused && threadIdx.x < 3)
+		{
+			out[3 * u.flow_idx + threadIdx.x] = 0.0;
+		}
+		return;
+	}
+	const int W3 = 3 * u.rw;
+	const int H3 = 3 * u.rh;
+	const int R = (H3 + tiles - 1) / tiles;
+	const int r0 = tile * R;
+	const int rows = min(R, H3 - r0);
+	double S[7] = {0, 0, 0, 0, 0, 0, 0};
+	double m0 = flows[2 * u.flow_idx];
+	double m1 = flows[2 * u.flow_idx + 1];
+	fd_offset(set, fdStep, m0, m1);
+	if (rows > 0)
+	{
+		const int plane = rows * W3;
+		double* red = lds + C * plane;
+		for (int i = threadIdx.x; i < C * plane; i += blockDim.x)
+		{
+			lds[i] = 0.0;
+		}
+		__syncthreads();
+		splat_rows<C>(events + u.ev_off, u.n_ev, u.rx, u.ry, u.rw, u.rh, r0, rows, m0, m1, c,
+					  lds, plane);
+		__syncthreads();
+		tile_sums<C>(lds, plane, red, S);
+	}
+	if (threadIdx.x == 0)
+	{
+#pragma unroll
+		for (int k = 0; k < 7; ++k)
+		{
+			part[k] = S[k];
+		}
+		if (fused)
+		{
+			double r, j0 = 0.0, j1 = 0.0;
+			variance_from_sums(S, C == 3, m0, m1, c.max_res, r, j0, j1);
+			out[3 * u.flow_idx + 0] = r;
+			out[3 * u.flow_idx + 1] = j0;
+			out[3 * u.flow_idx + 2] = j1;
+		}
+	}
+}
+
+// Adds the row tiles of each unit in tile order and finishes the objective.
+// flow sets: 1 (C = 1 or 3), or 5 value-only sets for central differences.
+__global__ void k_combine_variance(const Unit* __restrict__ units, int nUnits,
+								   const double* __restrict__ flows, int tiles, int sets,
+								   int channels, double fdStep,
+								   const double* __restrict__ partials, double* __restrict__ out,
+								   EvalConsts c)
+{
+	const int unit = blockIdx.x * blockDim.x + threadIdx.x;
+	if (unit >= nUnits)
+	{
+		return;
+	}
+	const Unit u = units[unit];
+	double res[5] = {0, 0, 0, 0, 0};
+	double j0 = 0.0, j1 = 0.0;
+	if (u.flags & kUnitActive)
+	{
+		for (int s = 0; s < sets; ++s)
+		{
+			double S[7] = {0, 0, 0, 0, 0, 0, 0};
+			const double* p =
+				partials + ((static_cast<size_t>(s) * nUnits + unit) * tiles) * kPartialStride;
+			for (int t = 0; t < tiles; ++t)
+			{
+				for (int k = 0; k < 7; ++k)
+				{
+					S[k] += p[t * kPartialStride + k];
+				}
+			}
+			double m0 = flows[2 * u.flow_idx];
+			double m1 = flows[2 * u.flow_idx + 1];
+			fd_offset(s, fdStep, m0, m1);
+			double a = 0.0, b = 0.0;
+			variance_from_sums(S, channels == 3, m0, m1, c.max_res, res[s], a, b);
+			if (s == 0)
+			{
+				j0 = a;
+				j1 = b;
+			}
+		}
+		if (sets == 5)
+		{
+			j0 = (res[1] - res[2]) / (2.0 * fdStep);
+			j1 = (res[3] - res[4]) / (2.0 * fdStep);
+		}
+	}
+	out[3 * u.flow_idx + 0] = res[0];
+	out[3 * u.flow_idx + 1] = j0;
+	out[3 * u.flow_idx + 2] = j1;
+}
+
+// Diagnostic: the image of warped events of one unit, tile by tile, to HBM.
+template <int C>
+__global__ void k_dump_image(const uint64_t* __restrict__ events, const Unit* __restrict__ units,
+							 int unit, const double* __restrict__ flow, int tiles,
+							 double* __restrict__ image, EvalConsts c)
+{
+	extern __shared__ double lds[];
+	const Unit u = units[unit];
+	const int W3 = 3 * u.rw;
+	const int H3 = 3 * u.rh;
+	const int R = (H3 + tiles - 1) / tiles;
+	const size_t full = static_cast<size_t>(W3) * H3;
+	for (int tile = 0; tile < tiles; ++tile)
+	{
+		const int r0 = tile * R;
+		const int rows = min(R, H3 - r0);
+		if (rows <= 0)
+		{
+			break;
+		}
+		const int plane = rows * W3;
+		for (int i = threadIdx.x; i < C * plane; i += blockDim.x)
+		{
+			lds[i] = 0.0;
+		}
+		__syncthreads();
+		splat_rows<C>(events + u.ev_off, u.n_ev, u.rx, u.ry, u.rw, u.rh, r0, rows, flow[0],
+					  flow[1], c, lds, plane);
+		__syncthreads();
+		for (int ch = 0; ch < C; ++ch)
+		{
+			for (int i = threadIdx.x; i < plane; i += blockDim.x)
+			{
+				image[ch * full + static_cast<size_t>(r0) * W3 + i] = lds[ch * plane + i];
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Device-resident solve, one workgroup per patch (EBO_SOLVE_INDEPENDENT).
+// Trust-region Levenberg-Marquardt exactly as ebo_solver_opts describes it
+// (Ceres 2.0: TrustRegionMinimizer, LevenbergMarquardtStrategy,
+// TrustRegionStepEvaluator) on a 1-residual / 2-parameter problem, options of
+// feature_detector.cpp:401-410.  Every thread carries the (uniform) solver state;
+// the objective is evaluated cooperatively.  No host round trips.
+// ---------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void eval_unit(const uint64_t* __restrict__ ev, const Unit& u,
+										   double m0, double m1, int tiles, const EvalConsts& c,
+										   double* lds, double& r, double& j0, double& j1)
+{
+	const int W3 = 3 * u.rw;
+	const int H3 = 3 * u.rh;
+	const int R = (H3 + tiles - 1) / tiles;
+	double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+	for (int tile = 0; tile < tiles; ++tile)
+	{
+		const int r0 = tile * R;
+		const int rows = min(R, H3 - r0);
+		if (rows <= 0)
+		{
+			break;
+		}
+		const int plane = rows * W3;
+		double* red = lds + C * R * W3;
+		__syncthreads();
+		for (int i = threadIdx.x; i < C * plane; i += blockDim.x)
+		{
+			lds[i] = 0.0;
+		}
+		__syncthreads();
+		splat_rows<C>(ev, u.n_ev, u.rx, u.ry, u.rw, u.rh, r0, rows, m0, m1, c, lds, plane);
+		__syncthreads();
+		double S[7];
+		tile_sums<C>(lds, plane, red, S);
+#pragma unroll
+		for (int k = 0; k < 7; ++k)
+		{
+			acc[k] += S[k];
+		}
+	}
+	j0 = 0.0;
+	j1 = 0.0;
+	variance_from_sums(acc, C == 3, m0, m1, c.max_res, r, j0, j1);
+}
+
+__global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __restrict__ events,
+									const Unit* __restrict__ units, int tiles3, int tiles1,
+									double* __restrict__ flowsOut, int32_t* __restrict__ stats,
+									EvalConsts c, SolveConsts o)
+{
+	extern __shared__ double lds[];
+	const Unit u = units[blockIdx.x];
+	const uint64_t* ev = events + u.ev_off;
+	int iteration = 0, evalsCost = 0, evalsJac = 0, termination = 0;
+	double best0 = 0.0, best1 = 0.0;
+
+	if (u.flags & kUnitActive)
+	{
+		double x0 = 0.0, x1 = 0.0;  // feature_detector.cpp:318-326
+		double f, J0, J1;
+		eval_unit<3>(ev, u, x0, x1, tiles3, c, lds, f, J0, J1);
+		evalsJac++;
+		double xCost = 0.5 * f * f;
+		termination = 1;
+		if (!isfinite(xCost))
+		{
+			termination = 2;
+		}
+		else
+		{
+			double g0 = J0 * f, g1 = J1 * f;
+			double sc0 = 1.0, sc1 = 1.0;
+			if (o.jacobi_scaling)
+			{
+				sc0 = 1.0 / (1.0 + sqrt(J0 * J0));
+				sc1 = 1.0 / (1.0 + sqrt(J1 * J1));
+			}
+			double j0 = J0 * sc0, j1 = J1 * sc1;
+			double xNorm = sqrt(x0 * x0 + x1 * x1);
+			double gradMax = fmax(fabs(g0), fabs(g1));
+			double minimumCost = xCost;
+			double seMinimum = xCost, seCurrent = xCost, seReference = xCost, seCandidate = xCost;
+			double seAccRef = 0.0, seAccCand = 0.0;
+			int seNumNonmono = 0;
+			double radius = o.initial_radius, decreaseFactor = 2.0;
+			bool reuseDiagonal = false, lastSuccessful = false;
+			double d0 = 0.0, d1 = 0.0;
+			int numInvalid = 0;
+
+			for (;;)
+			{
+				if (lastSuccessful && xCost < minimumCost)
+				{
+					minimumCost = xCost;
+					best0 = x0;
+					best1 = x1;
+				}
+				if (iteration >= o.max_num_iterations)
+				{
+					termination = 1;
+					break;
+				}
+				if (lastSuccessful && gradMax <= o.gradient_tolerance)
+				{
+					termination = 0;
+					break;
+				}
+				if (radius < o.min_radius)
+				{
+					termination = 0;
+					break;
+				}
+				iteration++;
+				lastSuccessful = false;
+
+				if (!reuseDiagonal)
+				{
+					d0 = fmin(fmax(j0 * j0, o.min_lm_diagonal), o.max_lm_diagonal);
+					d1 = fmin(fmax(j1 * j1, o.min_lm_diagonal), o.max_lm_diagonal);
+				}
+				const double l0 = sqrt(d0 / radius);
+				const double l1 = sqrt(d1 / radius);
+				reuseDiagonal = true;
+				// (J'J + D'D) y = J'f by Cholesky; step = -y.
+				const double h00 = j0 * j0 + l0 * l0;
+				const double h10 = j1 * j0;
+				const double h11 = j1 * j1 + l1 * l1;
+				bool valid = (h00 > 0.0) && isfinite(h00);
+				double s0 = 0.0, s1 = 0.0;
+				if (valid)
+				{
+					const double L00 = sqrt(h00);
+					const double L10 = h10 / L00;
+					const double dd = h11 - L10 * L10;
+					valid = (dd > 0.0) && isfinite(dd);
+					if (valid)
+					{
+						const double L11 = sqrt(dd);
+						double b0 = (j0 * f) / L00;
+						double b1 = ((j1 * f) - L10 * b0) / L11;
+						b1 = b1 / L11;
+						b0 = (b0 - L10 * b1) / L00;
+						valid = isfinite(b0) && isfinite(b1);
+						s0 = -b0;
+						s1 = -b1;
+					}
+				}
+				double modelCostChange = 0.0;
+				if (valid)
+				{
+					const double mr = j0 * s0 + j1 * s1;
+					modelCostChange = 0.0 - mr * (f + mr / 2.0);
+					valid = modelCostChange > 0.0;
+				}
+				if (!valid)
+				{
+					numInvalid++;
+					if (numInvalid >= o.max_invalid)
+					{
+						termination = 2;
+						break;
+					}
+					radius *= 0.5;
+					reuseDiagonal = true;
+					continue;
+				}
+				numInvalid = 0;
+				const double c0 = x0 + s0 * sc0;
+				const double c1 = x1 + s1 * sc1;
+				double fc, t0, t1;
+				eval_unit<1>(ev, u, c0, c1, tiles1, c, lds, fc, t0, t1);
+				evalsCost++;
+				double candCost = 0.5 * fc * fc;
+				if (!isfinite(candCost))
+				{
+					candCost = 1.7976931348623157e308;
+				}
+				const double e0 = x0 - c0, e1 = x1 - c1;
+				const double stepNorm = sqrt(e0 * e0 + e1 * e1);
+				if (stepNorm <= o.parameter_tolerance * (xNorm + o.parameter_tolerance))
+				{
+					termination = 0;
+					break;
+				}
+				const double costChange = xCost - candCost;
+				if (fabs(costChange) <= o.function_tolerance * xCost)
+				{
+					termination = 0;
+					break;
+				}
+				const double relDec = (seCurrent - candCost) / modelCostChange;
+				const double histDec = (seReference - candCost) / (seAccRef + modelCostChange);
+				const double quality = fmax(relDec, histDec);
+				if (quality > o.min_relative_decrease)
+				{
+					x0 = c0;
+					x1 = c1;
+					xNorm = sqrt(x0 * x0 + x1 * x1);
+					eval_unit<3>(ev, u, x0, x1, tiles3, c, lds, f, J0, J1);
+					evalsJac++;
+					xCost = 0.5 * f * f;
+					if (!isfinite(xCost))
+					{
+						termination = 2;
+						break;
+					}
+					g0 = J0 * f;
+					g1 = J1 * f;
+					j0 = J0 * sc0;
+					j1 = J1 * sc1;
+					gradMax = fmax(fabs(g0), fabs(g1));
+					lastSuccessful = true;
+					const double q = 2.0 * quality - 1.0;
+					radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+					radius = fmin(o.max_radius, radius);
+					decreaseFactor = 2.0;
+					reuseDiagonal = false;
+					seCurrent = candCost;
+					seAccCand += modelCostChange;
+					seAccRef += modelCostChange;
+					if (seCurrent < seMinimum)
+					{
+						seMinimum = seCurrent;
+						seNumNonmono = 0;
+						seCandidate = seCurrent;
+						seAccCand = 0.0;
+					}
+					else
+					{
+						++seNumNonmono;
+						if (seCurrent > seCandidate)
+						{
+							seCandidate = seCurrent;
+							seAccCand = 0.0;
+						}
+					}
+					if (seNumNonmono == o.max_nonmono)
+					{
+						seReference = seCandidate;
+						seAccRef = seAccCand;
+					}
+				}
+				else
+				{
+					radius = radius / decreaseFactor;
+					decreaseFactor *= 2.0;
+					reuseDiagonal = true;
+				}
+			}
+		}
+	}
+	if (threadIdx.x == 0)
+	{
+		flowsOut[2 * u.flow_idx] = best0;
+		flowsOut[2 * u.flow_idx + 1] = best1;
+		if (stats)
+		{
+			stats[4 * u.flow_idx + 0] = iteration;
+			stats[4 * u.flow_idx + 1] = evalsCost;
+			stats[4 * u.flow_idx + 2] = evalsJac;
+			stats[4 * u.flow_idx + 3] = termination;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Integer event-count images (bit-exact by construction: int32 adds commute).
+//   EBO_COUNT_INTEGRATED feature_detector.cpp:466-482
+//   EBO_COUNT_WARPED     feature_detector.cpp:433-463  round() = half away from zero
+//   EBO_COUNT_FIELD      feature_detector.cpp:270-295  float32 field (at<Vec2f>)
+// Workgroup = unit (its events are one contiguous range and share one flow).
+// ---------------------------------------------------------------------------
+__global__ void k_count_scatter(const uint64_t* __restrict__ events, const Unit* __restrict__ units,
+								int unitsPerWindow, int mode, const void* __restrict__ aux,
+								int32_t* __restrict__ counts, EvalConsts c)
+{
+	const Unit u = units[blockIdx.x];
+	const int w = blockIdx.x / unitsPerWindow;
+	const int P = c.npx * c.npy;
+	const size_t imgSize = static_cast<size_t>(c.image_w) * c.image_h;
+	int32_t* img = counts + static_cast<size_t>(w) * imgSize;
+	const uint64_t* ev = events + u.ev_off;
+	const bool stray = (u.flags & kUnitStray) != 0;
+	double m0 = 0.0, m1 = 0.0;
+	if (mode == 1 && !stray)
+	{
+		const double* flows = static_cast<const double*>(aux);
+		m0 = flows[2 * u.flow_idx];
+		m1 = flows[2 * u.flow_idx + 1];
+	}
+	for (uint32_t e = threadIdx.x; e < u.n_ev; e += blockDim.x)
+	{
+		int x, y, pos, dt;
+		unpack(ev[e], x, y, pos, dt);
+		int nx = x, ny = y;
+		if (mode != 0)
+		{
+			if (mode == 1 && stray)
+			{
+				// :436-441 with the index clamped at 0 (negative indices are undefined there)
+				const int px = max(min(x / c.patch_w, c.npx - 1), 0);
+				const int py = max(min(y / c.patch_h, c.npy - 1), 0);
+				const double* flows = static_cast<const double*>(aux);
+				m0 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px)];
+				m1 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px) + 1];
+			}
+			if (mode == 2)
+			{
+				if (x < 0 || x >= c.image_w || y < 0 || y >= c.image_h)
+				{
+					continue;
+				}
+				const float* field = static_cast<const float*>(aux) +
+									 2 * (static_cast<size_t>(w) * imgSize +
+										  static_cast<size_t>(y) * c.image_w + x);
+				m0 = static_cast<double>(field[0]);
+				m1 = static_cast<double>(field[1]);
+			}
+			const double dtw = static_cast<double>(dt + u.dt_win);
+			const double fx = static_cast<double>(x) + dtw * c.scale * m0;
+			const double fy = static_cast<double>(y) + dtw * c.scale * m1;
+			if (!convertible(fx) || !convertible(fy))
+			{
+				continue;
+			}
+			nx = static_cast<int>(round(fx));
+			ny = static_cast<int>(round(fy));
+		}
+		if (nx >= 0 && nx < c.image_w && ny >= 0 && ny < c.image_h)
+		{
+			atomicAdd(&img[static_cast<size_t>(ny) * c.image_w + nx], 1);
+		}
+	}
+}
+
+// int32 counts -> f64 image (the reference's CV_64F); re-zeroes the scratch.
+__global__ void k_counts_to_f64(int32_t* __restrict__ counts, double* __restrict__ image, size_t n)
+{
+	const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+	for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+	{
+		image[i] = static_cast<double>(counts[i]);
+		counts[i] = 0;
+	}
+}
+
+// Patch::integrateEvents (patch.cpp:65-85) / integrateMotionCompensatedEvents
+// (patch.cpp:87-130): signed counts in an LDS tile, one workgroup per patch.
+__global__ void k_patch_integrate(const uint64_t* __restrict__ events,
+								  const uint32_t* __restrict__ offsets,
+								  const double* __restrict__ rects, const double* __restrict__ traj,
+								  const uint64_t* __restrict__ nablaOff, double* __restrict__ nabla)
+{
+	extern __shared__ int tile[];
+	const int p = blockIdx.x;
+	const double rx = rects[4 * p + 0], ry = rects[4 * p + 1];
+	const double rw = rects[4 * p + 2], rh = rects[4 * p + 3];
+	const int cols = static_cast<int>(rw);
+	const int rows = static_cast<int>(rh);
+	double* out = nabla + nablaOff[p];
+	double dirX = 0.0, dirY = 0.0, tDif = 1.0;
+	bool mc = traj != nullptr;
+	if (mc)
+	{
+		if (traj[4 * p + 3] == 0.0)
+		{
+			return;  // patch.cpp:99-100 time test failed: image left untouched
+		}
+		dirX = traj[4 * p + 0];
+		dirY = traj[4 * p + 1];
+		tDif = traj[4 * p + 2];
+	}
+	for (int i = threadIdx.x; i < rows * cols; i += blockDim.x)
+	{
+		tile[i] = 0;
+	}
+	__syncthreads();
+	const uint32_t e0 = offsets[p], e1 = offsets[p + 1];
+	for (uint32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x)
+	{
+		int x, y, pos, dt;
+		unpack(events[e], x, y, pos, dt);
+		int ix = x, iy = y;
+		if (mc)
+		{
+			const double f = static_cast<double>(dt) / tDif;
+			const double cx = static_cast<double>(x) + f * dirX;
+			const double cy = static_cast<double>(y) + f * dirY;
+			if (!convertible(cx) || !convertible(cy))
+			{
+				continue;
+			}
+			ix = static_cast<int>(rint(cx));  // cv::saturate_cast<int>: half to even
+			iy = static_cast<int>(rint(cy));
+		}
+		const double dx = static_cast<double>(ix);
+		const double dy = static_cast<double>(iy);
+		if (rx <= dx && dx < rx + rw && ry <= dy && dy < ry + rh)
+		{
+			const int px = static_cast<int>(dx - rx);
+			const int py = static_cast<int>(dy - ry);
+			atomicAdd(&tile[py * cols + px], pos ? 1 : -1);
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < rows * cols; i += blockDim.x)
+	{
+		out[i] = static_cast<double>(tile[i]);
+	}
+}
+
+int check_launch()
+{
+	return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename K>
+int allow_big_lds(K kernel, size_t bytes)
+{
+	if (bytes <= 64 * 1024)
+	{
+		return 0;
+	}
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+							   hipFuncAttributeMaxDynamicSharedMemorySize,
+							   static_cast<int>(bytes)) == hipSuccess
+			   ? 0
+			   : -2;
+}
+
+}  // namespace
+
+int launch_eval_variance(const EvalLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (L.n_units == 0)
+	{
+		return 0;
+	}
+	const dim3 grid(L.n_units * L.tiles, L.flow_sets);
+	auto kern = (L.channels == 3) ? k_eval_variance<3> : k_eval_variance<1>;
+	if (allow_big_lds(kern, L.lds_bytes))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
+					   L.d_flows, L.tiles, L.fd_step, L.d_partials, L.d_out, L.c);
+	if (check_launch())
+	{
+		return -2;
+	}
+	if (!(L.tiles == 1 && L.flow_sets == 1))
+	{
+		hipLaunchKernelGGL(k_combine_variance, dim3((L.n_units + 127) / 128), dim3(128), 0, s,
+						   L.d_units, L.n_units, L.d_flows, L.tiles, L.flow_sets, L.channels,
+						   L.fd_step, L.d_partials, L.d_out, L.c);
+	}
+	return check_launch();
+}
+
+int launch_dump_image(const EvalLaunch& L, int unit, double* d_image, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	auto kern = (L.channels == 3) ? k_dump_image<3> : k_dump_image<1>;
+	if (allow_big_lds(kern, L.lds_bytes))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(kern, dim3(1), dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units, unit,
+					   L.d_flows, L.tiles, d_image, L.c);
+	return check_launch();
+}
+
+int launch_solve_independent(const SolveLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (L.n_units == 0)
+	{
+		return 0;
+	}
+	if (allow_big_lds(k_solve_independent, L.lds_bytes))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_solve_independent, dim3(L.n_units), dim3(L.block), L.lds_bytes, s,
+					   L.d_events, L.d_units, L.tiles3, L.tiles1, L.d_flows_out, L.d_stats, L.c,
+					   L.s);
+	return check_launch();
+}
+
+int launch_count_image(const CountLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const size_t n = static_cast<size_t>(L.n_windows) * L.c.image_w * L.c.image_h;
+	if (L.n_units_total > 0)
+	{
+		hipLaunchKernelGGL(k_count_scatter, dim3(L.n_units_total), dim3(256), 0, s, L.d_events,
+						   L.d_units, L.units_per_window, L.mode, L.d_aux, L.d_counts, L.c);
+		if (check_launch())
+		{
+			return -2;
+		}
+	}
+	const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 2048));
+	hipLaunchKernelGGL(k_counts_to_f64, dim3(blocks), dim3(256), 0, s, L.d_counts, L.d_image, n);
+	return check_launch();
+}
+
+int launch_patch_integrate(const PatchIntLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (L.n_patches == 0)
+	{
+		return 0;
+	}
+	const size_t lds = 64 * 1024;  // tiles up to 16384 pixels (default patch is 25x25)
+	hipLaunchKernelGGL(k_patch_integrate, dim3(L.n_patches), dim3(256), lds, s, L.d_events,
+					   L.d_offsets, L.d_rects, L.d_traj, L.d_nabla_off, L.d_nabla);
+	return check_launch();
+}
+
+}  // namespace ebo

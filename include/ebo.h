@@ -1,0 +1,225 @@
+/*
+ * ebo.h — C ABI of libebo_hip.so: the MI355X (gfx950) implementation of the
+ * motion-compensated event-warping path of nurlanov-zh/event-based-odomety.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no C++ types, no
+ * torch types.  Nothing allocates across the ABI: the context owns every device
+ * buffer, the caller owns every host pointer it passes in or gets results in.
+ * Every function returns an int status (0 = ok, negative = error) and never
+ * throws; ebo_last_error() gives the message.  A context belongs to one thread and
+ * one device.  There is NO CPU fallback: without a gfx950 device ebo_create fails
+ * with EBO_ERR_NO_DEVICE.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   R1  ceres::AutoDiffCostFunction<tracker::contrastFunctor,1,2>::Evaluate
+ *       built at implementation/feature_tracker/src/feature_detector.cpp:359-363 on
+ *       implementation/feature_tracker/include/feature_tracker/contrast_functor.h:10-292
+ *   R2  tracker::FeatureDetector::compensateEventsContrast   feature_detector.cpp:298-464
+ *   R3  tracker::FeatureDetector::integrateEvents            feature_detector.cpp:466-482
+ *   R4  tracker::FeatureDetector::compensateEvents           feature_detector.cpp:243-296
+ *   R5  tracker::Patch::integrateEvents                      implementation/feature_tracker/src/patch.cpp:65-85
+ *   R6  tracker::Patch::integrateMotionCompensatedEvents     patch.cpp:87-130
+ *   R7  tracker::DetectorParams                              include/feature_tracker/feature_detector.h:10-31
+ *   R8  common::EventSample                                  common/include/common/data_types.h:12-38
+ * The C++ façade with the reference's own names (tracker::FeatureDetector,
+ * tracker::contrastFunctor, ...) sits on top of this header in
+ * event-based-odomety_amd/include/; INTEGRATION.md shows the binding.
+ */
+#ifndef EBO_H
+#define EBO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBO_OK 0
+#define EBO_ERR_ARG (-1)         /* null pointer, bad size, bad enum          */
+#define EBO_ERR_HIP (-2)         /* a HIP runtime call failed                  */
+#define EBO_ERR_RANGE (-3)       /* coordinate / timestamp outside packed range */
+#define EBO_ERR_STATE (-4)       /* call order (no window set, ...)           */
+#define EBO_ERR_UNSUPPORTED (-5) /* parameter combination not built            */
+#define EBO_ERR_NO_DEVICE (-6)   /* no HIP device / not gfx950                 */
+#define EBO_ERR_SOLVER (-7)      /* solver terminated with FAILURE             */
+
+#define EBO_LOSS_EDGE 0     /* contrastFunctor::calculateEdgeLoss (reference default, :152-277) */
+#define EBO_LOSS_VARIANCE 1 /* contrastFunctor::calculateVarianceLoss (:101-150, north-star objective) */
+
+#define EBO_GRAD_JET 0     /* forward-mode dual numbers == ceres::Jet<double,2> (reference) */
+#define EBO_GRAD_CENTRAL 1 /* central differences of the value-only objective */
+
+#define EBO_SOLVE_GLOBAL 0      /* one problem over all patches incl. TV terms (reference, R2) */
+#define EBO_SOLVE_INDEPENDENT 1 /* one 2-parameter problem per patch, solved on the device   */
+
+#define EBO_COUNT_INTEGRATED 0 /* R3: un-warped counts                                  */
+#define EBO_COUNT_WARPED 1     /* R2 final loop (:433-463): warp by per-patch flow, round() */
+#define EBO_COUNT_FIELD 2      /* R4 warp loop (:270-295): warp by float32 per-pixel field  */
+
+typedef struct ebo_ctx ebo_ctx;
+
+/* R8: layout-compatible with common::EventSample on LP64
+ * ({cv::Point2i{x,y}; enum EventPolarity sign; std::chrono::microseconds}). */
+typedef struct ebo_event
+{
+	int32_t x;
+	int32_t y;
+	int32_t sign; /* -1 / +1 */
+	int32_t reserved;
+	int64_t t_us;
+} ebo_event;
+
+/* contrastFunctor's hard-coded members, contrast_functor.h:282-291. */
+typedef struct ebo_functor_consts
+{
+	double max_possible_residual; /* 1e3 */
+	double sigma_compensate;      /* 1   */
+	int32_t kernel_compensate;    /* 3 (only 3 is built)  */
+	int32_t kernel_st;            /* 3 (only 3 is built)  */
+	double sigma_st;              /* 1.5 */
+	int32_t kernel_nms;           /* 2 (only 2 is built)  */
+	int32_t reserved;
+} ebo_functor_consts;
+
+/* R7: the DetectorParams fields this path reads, same defaults. */
+typedef struct ebo_params
+{
+	int32_t device;           /* HIP device ordinal                         */
+	int32_t image_w, image_h; /* imageSize {240,180}                        */
+	int32_t patch_w, patch_h; /* patchCompensateSize {20,20}                */
+	double tv_weight;         /* compensateTVweight 1e3                     */
+	double tv_huber;          /* compensateTVHuberLoss 10                   */
+	double scale;             /* compensateScale 1e-3                       */
+	uint32_t min_events;      /* compensateMinNumEvents 100                 */
+	int32_t loss;             /* EBO_LOSS_*  (default EDGE, as the reference) */
+	int32_t grad;             /* EBO_GRAD_*  (default JET, as the reference)  */
+	int32_t reserved;
+	double fd_step;           /* step for EBO_GRAD_CENTRAL (default 1e-6)   */
+	ebo_functor_consts k;
+	uint64_t max_events;      /* device capacity, events over all windows of a batch (default 1<<20) */
+	int32_t max_windows;      /* device capacity, windows per batch (default 1) */
+	int32_t reserved2;
+} ebo_params;
+
+/* ceres::Solver::Options as set at feature_detector.cpp:401-410; unset fields
+ * carry Ceres 2.0 defaults. */
+typedef struct ebo_solver_opts
+{
+	int32_t max_num_iterations; /* 50    */
+	int32_t use_nonmonotonic;   /* 1     */
+	double function_tolerance;  /* 1e-12 */
+	double gradient_tolerance;  /* 1e-12 */
+	double parameter_tolerance; /* 1e-12 */
+	double initial_radius;      /* 1e4   */
+	double max_radius;          /* 1e16  */
+	double min_radius;          /* 1e-32 */
+	double min_relative_decrease; /* 1e-3 */
+	double min_lm_diagonal;     /* 1e-6  */
+	double max_lm_diagonal;     /* 1e32  */
+	int32_t max_consecutive_nonmonotonic; /* 5 */
+	int32_t max_consecutive_invalid;      /* 5 */
+	int32_t jacobi_scaling;     /* 1 */
+	int32_t mode;               /* EBO_SOLVE_* */
+} ebo_solver_opts;
+
+typedef struct ebo_summary
+{
+	int32_t iterations;     /* LM iterations (global) / max over patches (independent) */
+	int32_t num_evals_cost; /* value-only evaluations of data terms     */
+	int32_t num_evals_jac;  /* value+Jacobian evaluations of data terms */
+	int32_t termination;    /* 0 convergence, 1 no convergence, 2 failure */
+	double initial_cost;
+	double final_cost;
+} ebo_summary;
+
+const char* ebo_version(void);
+/* Number of HIP devices; 0 (and EBO_OK) when there is none. */
+int ebo_device_count(int* n);
+void ebo_default_params(ebo_params* p);
+void ebo_default_solver(ebo_solver_opts* o);
+/* Last error text of ctx (or of the calling thread's last failed ebo_create when ctx is NULL). */
+const char* ebo_last_error(const ebo_ctx* ctx);
+
+int ebo_create(const ebo_params* p, ebo_ctx** out);
+void ebo_destroy(ebo_ctx* ctx);
+/* Launch on this HIP stream (hipStream_t) instead of the context's own. */
+int ebo_set_stream(ebo_ctx* ctx, void* hip_stream);
+int ebo_synchronize(ebo_ctx* ctx);
+
+/* Patch grid of R2 (:301-346): npx*npy patches, last row/column absorb the remainder. */
+int ebo_grid(const ebo_ctx* ctx, int* npx, int* npy);
+int ebo_patch_rect(const ebo_ctx* ctx, int px, int py, int* x, int* y, int* w, int* h);
+
+/* Load one window (the `events` list R2/R3/R4 receive), time-ordered as given.
+ * The host buckets events by patch keeping their order (R2 :348-355), computes
+ * the window's and each patch's reference time (:305-306, contrast_functor.h:18-20),
+ * packs 8 B/event and uploads.  Replaces any previous window(s). */
+int ebo_set_window(ebo_ctx* ctx, const ebo_event* ev, size_t n);
+/* Batch of independent windows: window w = ev[offsets[w] .. offsets[w+1]). */
+int ebo_set_windows(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets, int n_windows);
+int ebo_num_windows(const ebo_ctx* ctx, int* n_windows);
+int ebo_window_info(const ebo_ctx* ctx, int window, int64_t* t_ref_us, uint64_t* n_events);
+/* n_events in the patch, active = (n_events > min_events), functor reference time. */
+int ebo_patch_info(const ebo_ctx* ctx, int window, int patch, int32_t* n_events,
+				   int32_t* active, int64_t* t_ref_us);
+
+/* R1, batched over every patch of every loaded window: residual r and (if jac
+ * != NULL) the 1x2 Jacobian at flows[w][p][0..1].  Inactive patches give 0.
+ * Host pointers: flows [Wn][P][2], r [Wn][P], jac [Wn][P][2]. Synchronous. */
+int ebo_eval(ebo_ctx* ctx, const double* flows, double* r, double* jac);
+/* Same on device pointers, asynchronous on the context's stream:
+ * d_flows [Wn][P][2], d_out [Wn][P][3] = (r, J0, J1). */
+int ebo_eval_device(ebo_ctx* ctx, const double* d_flows, int want_jac, double* d_out);
+/* The image of warped events the functor builds for one patch at one flow
+ * (contrast_functor.h:38-88): planar [channels][3h][3w], channels = 1 or 3. Diagnostic. */
+int ebo_contrast_image(ebo_ctx* ctx, int window, int patch, const double* flow,
+					   int channels, double* image);
+
+/* Solve for the flows of every loaded window starting from 0 (R2 :316-414).
+ * flows_out host [Wn][P][2]; summary [Wn] (may be NULL). */
+int ebo_solve(ebo_ctx* ctx, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary);
+/* EBO_SOLVE_INDEPENDENT only: the whole solve in one launch, result left on the
+ * device in d_flows_out [Wn][P][2]; asynchronous. d_stats (may be NULL) [Wn][P][4]
+ * int32 = (iterations, value evals, jacobian evals, termination). */
+int ebo_solve_device(ebo_ctx* ctx, const ebo_solver_opts* o, double* d_flows_out,
+					 int32_t* d_stats);
+
+/* Integer-valued event-count images (CV_64F in the reference), host out
+ * [Wn][image_h][image_w].  aux: EBO_COUNT_WARPED -> host flows [Wn][P][2];
+ * EBO_COUNT_FIELD -> host float32 field [Wn][image_h][image_w][2]; else NULL. */
+int ebo_count_image(ebo_ctx* ctx, int mode, const void* aux, double* image);
+/* Same with aux and image on the device; asynchronous. */
+int ebo_count_image_device(ebo_ctx* ctx, int mode, const void* d_aux, double* d_image);
+
+/* R2 in one call: set window, solve, final warped count image.
+ * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */
+int ebo_compensate_events_contrast(ebo_ctx* ctx, const ebo_event* ev, size_t n,
+								   const ebo_solver_opts* o, double* flows_out,
+								   double* image_out, ebo_summary* summary);
+
+/* R5/R6 batched over tracked feature patches.  Patch i owns events
+ * ev[offsets[i]..offsets[i+1]) in deque order (front = newest), a cv::Rect2d
+ * rects[i][4] = (x,y,w,h), and writes a [int(h)][int(w)] signed count image at
+ * nabla + nabla_offsets[i].  For R6, traj[i][6] = (prelast x,y,t_us, last x,y,t_us)
+ * and mid_time[i]; updated[i] tells whether R6's time test passed. */
+int ebo_patch_integrate(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets,
+						int n_patches, const double* rects, const size_t* nabla_offsets,
+						double* nabla, int64_t* current_ts, int64_t* time_last_update);
+int ebo_patch_integrate_mc(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets,
+						   int n_patches, const double* rects, const double* traj,
+						   const int64_t* mid_time, const size_t* nabla_offsets,
+						   double* nabla, int32_t* updated);
+
+/* Contiguous shard [begin,end) of n_units for rank of world (multi-GPU, §8e). */
+int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end);
+
+/* Device-side timing of everything enqueued between begin and end on the
+ * context's stream (hipEvent based). */
+int ebo_timer_begin(ebo_ctx* ctx);
+int ebo_timer_end(ebo_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBO_H */

@@ -1,0 +1,194 @@
+/*
+ * ebo_oracle.h — C API of the CPU ORACLE.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.  The product (libebo_hip.so)
+ * never links, loads or calls anything in oracle/.
+ *
+ * What it is: a plain single-threaded C++ restatement of the reference's
+ * motion-compensation hot path (reference = nurlanov-zh/event-based-odomety,
+ * paths below are relative to the reference checkout):
+ *   implementation/feature_tracker/include/feature_tracker/contrast_functor.h
+ *   implementation/feature_tracker/include/feature_tracker/total_variance.h
+ *   implementation/feature_tracker/src/feature_detector.cpp:243-482
+ *   implementation/feature_tracker/src/patch.cpp:65-130
+ *   tools/dataset_reader/src/davis240c_reader.cpp:60-92
+ * Every function cites the lines it follows in oracle.cpp.
+ *
+ * PARITY PINNING STATUS
+ *   - The reference cannot be built in this image: it needs Ceres, Eigen 3.3.7, OpenCV,
+ *     Sophus and spdlog, none of which are installed, and thirdparty/ is empty.  No
+ *     stand-in headers were written to force a build.
+ *   - Pinned by the reference's own tests: Patch::integrateEvents known-answer
+ *     (implementation/feature_tracker/test/patch_test.cpp:35-60), event->patch
+ *     membership (feature_detector_test.cpp:43-97), DAVIS event text fixture
+ *     (tools/dataset_reader/test/davis240c_reader_test.cpp:19-48 + test_data/events.txt).
+ *   - contrastFunctor value/Jacobian: cross-checked against the digits recorded in
+ *     SURVEY.md §8(c) (tests/golden/survey_probe_contrast.json); the reference's own
+ *     tests do not exercise it.
+ *   - Solver trajectory (Ceres trust-region LM): PARITY UNPINNED.  Ceres is a
+ *     third-party dependency (thirdparty/ceres-solver, >=2.0,<2.2, commit unknown) that is
+ *     absent here; oracle.cpp restates its published Levenberg-Marquardt trust-region
+ *     algorithm (docs "Solving Non-linear Least Squares", TrustRegionMinimizer /
+ *     LevenbergMarquardtStrategy / TrustRegionStepEvaluator, v2.0 defaults).
+ */
+#ifndef EBO_ORACLE_H
+#define EBO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirror of common::EventSample (common/include/common/data_types.h:12-38):
+ * {Point2i{x,y}; EventPolarity sign(-1/+1); microseconds timestamp}. 24 bytes. */
+typedef struct orc_event
+{
+	int32_t x;
+	int32_t y;
+	int32_t sign;
+	int32_t reserved;
+	int64_t t_us;
+} orc_event;
+
+/* contrastFunctor's hard-coded members (contrast_functor.h:282-291). */
+typedef struct orc_functor_consts
+{
+	double max_possible_residual; /* 1e3 */
+	double sigma_compensate;      /* 1   */
+	int32_t kernel_compensate;    /* 3   */
+	int32_t kernel_st;            /* 3   */
+	double sigma_st;              /* 1.5 */
+	int32_t kernel_nms;           /* 2   */
+	int32_t reserved;
+} orc_functor_consts;
+
+/* DetectorParams fields on the hot path (feature_detector.h:17,21-30). */
+typedef struct orc_params
+{
+	int32_t image_w, image_h;               /* imageSize {240,180}            */
+	int32_t patch_w, patch_h;               /* patchCompensateSize {20,20}    */
+	double tv_weight;                       /* compensateTVweight 1e3         */
+	double tv_huber;                        /* compensateTVHuberLoss 10       */
+	double scale;                           /* compensateScale 1e-3           */
+	uint32_t min_events;                    /* compensateMinNumEvents 100     */
+	int32_t loss;                           /* 0 = edge (reference), 1 = variance */
+	orc_functor_consts k;
+} orc_params;
+
+/* ceres::Solver::Options as set at feature_detector.cpp:401-410; the rest are
+ * Ceres 2.0 defaults. */
+typedef struct orc_solver_opts
+{
+	int32_t max_num_iterations;   /* 50    */
+	int32_t use_nonmonotonic;     /* 1     */
+	double function_tolerance;    /* 1e-12 */
+	double gradient_tolerance;    /* 1e-12 */
+	double parameter_tolerance;   /* 1e-12 */
+	double initial_radius;        /* 1e4   */
+	double max_radius;            /* 1e16  */
+	double min_radius;            /* 1e-32 */
+	double min_relative_decrease; /* 1e-3  */
+	double min_lm_diagonal;       /* 1e-6  */
+	double max_lm_diagonal;       /* 1e32  */
+	int32_t max_consecutive_nonmonotonic; /* 5 */
+	int32_t max_consecutive_invalid;      /* 5 */
+	int32_t jacobi_scaling;       /* 1 */
+	int32_t mode;                 /* 0 = one global problem (reference), 1 = one problem per patch */
+} orc_solver_opts;
+
+typedef struct orc_summary
+{
+	int32_t iterations;        /* LM iterations run (global) or max over patches */
+	int32_t num_evals_cost;    /* residual-only evaluations of data blocks     */
+	int32_t num_evals_jac;     /* residual+Jacobian evaluations of data blocks */
+	int32_t termination;       /* 0 conv, 1 no-conv (max iters), 2 failure     */
+	double initial_cost;
+	double final_cost;
+} orc_summary;
+
+void orc_default_consts(orc_functor_consts* k);
+void orc_default_params(orc_params* p);
+void orc_default_solver(orc_solver_opts* o);
+
+/* contrastFunctor::operator() on one patch (contrast_functor.h:12-36).
+ * ev = the patch's events in list order (front = oldest).
+ * jac may be NULL (value-only, i.e. the T=double instantiation). */
+int orc_contrast_eval(const orc_event* ev, size_t n, int rx, int ry, int rw,
+					  int rh, double scale, const orc_functor_consts* k,
+					  int loss, const double* motion, double* residual,
+					  double* jac);
+
+/* The image built by contrastFunctor::compensateEvents (contrast_functor.h:38-88).
+ * img: planar [c][3*rh][3*rw], c = 1 (value) or 3 (value, d/dm0, d/dm1). */
+int orc_contrast_image(const orc_event* ev, size_t n, int rx, int ry, int rw,
+					   int rh, double scale, const orc_functor_consts* k,
+					   const double* motion, int channels, double* img);
+
+/* contrastFunctor's reference time (contrast_functor.h:18-20). */
+int64_t orc_mid_timestamp(int64_t front_us, int64_t back_us);
+
+/* totalVarianceFunctor (total_variance.h:14-20): r[2], jx/jy 2x2 row-major (may be NULL). */
+int orc_tv_eval(double weight, const double* x, const double* y, double* r,
+				double* jx, double* jy);
+
+/* Patch grid of compensateEventsContrast (feature_detector.cpp:301-346). */
+int orc_grid(const orc_params* p, int* npx, int* npy);
+int orc_patch_rect(const orc_params* p, int px, int py, int* rx, int* ry,
+				   int* rw, int* rh);
+
+/* Batched objective over the whole window at given flows [P][2]:
+ * bucketing feature_detector.cpp:348-367, one contrastFunctor per patch.
+ * active[p] = 1 iff patch p has > min_events events. r[P], jac[P][2] (jac may be NULL). */
+int orc_window_eval(const orc_event* ev, size_t n, const orc_params* p,
+					const double* flows, double* r, double* jac,
+					int32_t* active, int32_t* counts);
+
+/* FeatureDetector::compensateEventsContrast (feature_detector.cpp:298-464):
+ * flows [P][2] out, image [image_h][image_w] out (may be NULL). */
+int orc_compensate_events_contrast(const orc_event* ev, size_t n,
+								   const orc_params* p,
+								   const orc_solver_opts* o, double* flows,
+								   double* image, orc_summary* summary);
+
+/* Only the final warped count image of compensateEventsContrast
+ * (feature_detector.cpp:433-463) for given flows. */
+int orc_final_count_image(const orc_event* ev, size_t n, const orc_params* p,
+						  const double* flows, double* image);
+
+/* FeatureDetector::integrateEvents (feature_detector.cpp:466-482). */
+int orc_integrate_events(const orc_event* ev, size_t n, int w, int h,
+						 double* image);
+
+/* FeatureDetector::compensateEvents' warp loop (feature_detector.cpp:246-295)
+ * with a given float32 motion field [h][w][2] (the at<Vec2f> view). */
+int orc_compensate_events_field(const orc_event* ev, size_t n, int w, int h,
+								double scale, const float* field,
+								double* image);
+
+/* Patch::integrateEvents (patch.cpp:65-85). ev in deque order (front = newest).
+ * nabla [int(rh)][int(rw)]. */
+int orc_patch_integrate(const orc_event* ev, size_t n, double rx, double ry,
+						double rw, double rh, double* nabla,
+						int64_t* current_ts, int64_t* time_last_update);
+
+/* Patch::integrateMotionCompensatedEvents (patch.cpp:87-130).
+ * traj: last two trajectory samples {x,y,t_us} (prelast, last). Returns 1 in
+ * *updated if the image was rebuilt. */
+int orc_patch_integrate_mc(const orc_event* ev, size_t n, double rx, double ry,
+						   double rw, double rh, const double* prelast_xy,
+						   int64_t prelast_t, const double* last_xy,
+						   int64_t last_t, int64_t mid_time, double* nabla,
+						   int32_t* updated);
+
+/* Davis240cReader::getEventSample over a whole events.txt
+ * (davis240c_reader.cpp:60-92). Returns number parsed in *n (<= cap). */
+int orc_parse_events_txt(const char* path, orc_event* out, size_t cap,
+						 size_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,33 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ebo():
+    """The product's ctypes plumbing (event-based-odomety_amd/__init__.py)."""
+    return importlib.import_module("event-based-odomety_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("event-based-odomety_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure)."""
+    import orc as _orc
+    _orc.lib()
+    return _orc

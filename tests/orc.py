@@ -1,0 +1,285 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+# numpy mirror of orc_event / ebo_event / common::EventSample (24 bytes)
+EVENT_DTYPE = np.dtype(
+    [("x", "<i4"), ("y", "<i4"), ("sign", "<i4"), ("reserved", "<i4"), ("t_us", "<i8")]
+)
+assert EVENT_DTYPE.itemsize == 24
+
+
+class FunctorConsts(C.Structure):
+    _fields_ = [
+        ("max_possible_residual", C.c_double),
+        ("sigma_compensate", C.c_double),
+        ("kernel_compensate", C.c_int32),
+        ("kernel_st", C.c_int32),
+        ("sigma_st", C.c_double),
+        ("kernel_nms", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("image_w", C.c_int32),
+        ("image_h", C.c_int32),
+        ("patch_w", C.c_int32),
+        ("patch_h", C.c_int32),
+        ("tv_weight", C.c_double),
+        ("tv_huber", C.c_double),
+        ("scale", C.c_double),
+        ("min_events", C.c_uint32),
+        ("loss", C.c_int32),
+        ("k", FunctorConsts),
+    ]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("use_nonmonotonic", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double),
+        ("max_radius", C.c_double),
+        ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("max_consecutive_nonmonotonic", C.c_int32),
+        ("max_consecutive_invalid", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("mode", C.c_int32),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("num_evals_cost", C.c_int32),
+        ("num_evals_jac", C.c_int32),
+        ("termination", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_mid_timestamp.restype = C.c_int64
+        _lib.orc_mid_timestamp.argtypes = [C.c_int64, C.c_int64]
+    return _lib
+
+
+def _evp(ev):
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    return ev, ev.ctypes.data_as(C.c_void_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_events(x, y, t_us, sign=None):
+    n = len(x)
+    ev = np.zeros(n, dtype=EVENT_DTYPE)
+    ev["x"] = x
+    ev["y"] = y
+    ev["t_us"] = t_us
+    ev["sign"] = 1 if sign is None else sign
+    return ev
+
+
+def default_consts():
+    k = FunctorConsts()
+    lib().orc_default_consts(C.byref(k))
+    return k
+
+
+def default_params(**kw):
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    for key, val in kw.items():
+        setattr(p, key, val)
+    return p
+
+
+def default_solver(**kw):
+    o = SolverOpts()
+    lib().orc_default_solver(C.byref(o))
+    for key, val in kw.items():
+        setattr(o, key, val)
+    return o
+
+
+def contrast_eval(ev, rect, motion, loss, want_jac=True, scale=1e-3, consts=None):
+    """contrastFunctor::operator() on one patch. Returns (r, J or None)."""
+    ev, p = _evp(ev)
+    k = consts or default_consts()
+    m = np.asarray(motion, dtype=np.float64)
+    r = C.c_double()
+    J = np.zeros(2)
+    rc = lib().orc_contrast_eval(
+        p, C.c_size_t(len(ev)), *[int(v) for v in rect], C.c_double(scale), C.byref(k),
+        int(loss), _dp(m), C.byref(r), _dp(J) if want_jac else None)
+    assert rc == 0
+    return r.value, (J if want_jac else None)
+
+
+def contrast_image(ev, rect, motion, channels=3, scale=1e-3, consts=None):
+    ev, p = _evp(ev)
+    k = consts or default_consts()
+    m = np.asarray(motion, dtype=np.float64)
+    img = np.zeros((channels, 3 * rect[3], 3 * rect[2]))
+    rc = lib().orc_contrast_image(
+        p, C.c_size_t(len(ev)), *[int(v) for v in rect], C.c_double(scale), C.byref(k),
+        _dp(m), int(channels), _dp(img))
+    assert rc == 0
+    return img
+
+
+def tv_eval(weight, x, y):
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    r = np.zeros(2)
+    jx = np.zeros((2, 2))
+    jy = np.zeros((2, 2))
+    rc = lib().orc_tv_eval(C.c_double(weight), _dp(x), _dp(y), _dp(r), _dp(jx), _dp(jy))
+    assert rc == 0
+    return r, jx, jy
+
+
+def grid(prm):
+    npx, npy = C.c_int(), C.c_int()
+    assert lib().orc_grid(C.byref(prm), C.byref(npx), C.byref(npy)) == 0
+    return npx.value, npy.value
+
+
+def patch_rect(prm, px, py):
+    v = [C.c_int() for _ in range(4)]
+    assert lib().orc_patch_rect(C.byref(prm), px, py, *[C.byref(a) for a in v]) == 0
+    return tuple(a.value for a in v)
+
+
+def window_eval(ev, prm, flows, want_jac=True):
+    ev, p = _evp(ev)
+    npx, npy = grid(prm)
+    P = npx * npy
+    flows = np.ascontiguousarray(flows, dtype=np.float64).reshape(P, 2)
+    r = np.zeros(P)
+    J = np.zeros((P, 2))
+    active = np.zeros(P, dtype=np.int32)
+    counts = np.zeros(P, dtype=np.int32)
+    rc = lib().orc_window_eval(
+        p, C.c_size_t(len(ev)), C.byref(prm), _dp(flows), _dp(r),
+        _dp(J) if want_jac else None, active.ctypes.data_as(C.c_void_p),
+        counts.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return r, (J if want_jac else None), active, counts
+
+
+def compensate_events_contrast(ev, prm, opts=None, want_image=True):
+    ev, p = _evp(ev)
+    opts = opts or default_solver()
+    npx, npy = grid(prm)
+    flows = np.zeros((npx * npy, 2))
+    img = np.zeros((prm.image_h, prm.image_w)) if want_image else None
+    s = Summary()
+    rc = lib().orc_compensate_events_contrast(
+        p, C.c_size_t(len(ev)), C.byref(prm), C.byref(opts), _dp(flows),
+        _dp(img) if want_image else None, C.byref(s))
+    assert rc == 0
+    return flows, img, s
+
+
+def final_count_image(ev, prm, flows):
+    ev, p = _evp(ev)
+    flows = np.ascontiguousarray(flows, dtype=np.float64)
+    img = np.zeros((prm.image_h, prm.image_w))
+    rc = lib().orc_final_count_image(p, C.c_size_t(len(ev)), C.byref(prm), _dp(flows), _dp(img))
+    assert rc == 0
+    return img
+
+
+def integrate_events(ev, w, h):
+    ev, p = _evp(ev)
+    img = np.zeros((h, w))
+    assert lib().orc_integrate_events(p, C.c_size_t(len(ev)), int(w), int(h), _dp(img)) == 0
+    return img
+
+
+def compensate_events_field(ev, w, h, field, scale=1e-3):
+    ev, p = _evp(ev)
+    field = np.ascontiguousarray(field, dtype=np.float32).reshape(h, w, 2)
+    img = np.zeros((h, w))
+    rc = lib().orc_compensate_events_field(
+        p, C.c_size_t(len(ev)), int(w), int(h), C.c_double(scale),
+        field.ctypes.data_as(C.c_void_p), _dp(img))
+    assert rc == 0
+    return img
+
+
+def patch_integrate(ev, rect):
+    """Patch::integrateEvents; ev in deque order (front = newest)."""
+    ev, p = _evp(ev)
+    rx, ry, rw, rh = [float(v) for v in rect]
+    nabla = np.zeros((int(rh), int(rw)))
+    cur, last = C.c_int64(), C.c_int64()
+    rc = lib().orc_patch_integrate(
+        p, C.c_size_t(len(ev)), C.c_double(rx), C.c_double(ry), C.c_double(rw),
+        C.c_double(rh), _dp(nabla), C.byref(cur), C.byref(last))
+    assert rc == 0
+    return nabla, cur.value, last.value
+
+
+def patch_integrate_mc(ev, rect, prelast, last, mid_time):
+    """Patch::integrateMotionCompensatedEvents; prelast/last = (x, y, t_us)."""
+    ev, p = _evp(ev)
+    rx, ry, rw, rh = [float(v) for v in rect]
+    nabla = np.zeros((int(rh), int(rw)))
+    a = np.asarray(prelast[:2], dtype=np.float64)
+    b = np.asarray(last[:2], dtype=np.float64)
+    upd = C.c_int32()
+    rc = lib().orc_patch_integrate_mc(
+        p, C.c_size_t(len(ev)), C.c_double(rx), C.c_double(ry), C.c_double(rw),
+        C.c_double(rh), _dp(a), C.c_int64(int(prelast[2])), _dp(b), C.c_int64(int(last[2])),
+        C.c_int64(int(mid_time)), _dp(nabla), C.byref(upd))
+    assert rc == 0
+    return nabla, bool(upd.value)
+
+
+def parse_events_txt(path, cap=1 << 20):
+    out = np.zeros(cap, dtype=EVENT_DTYPE)
+    n = C.c_size_t()
+    rc = lib().orc_parse_events_txt(
+        path.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(n))
+    return rc, out[: n.value].copy()
+
+
+def mid_timestamp(front, back):
+    return lib().orc_mid_timestamp(int(front), int(back))

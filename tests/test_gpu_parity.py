@@ -1,0 +1,381 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bars:
+  * integer count images: bit-exact (np.array_equal)
+  * objective value / Jacobian: relative 1e-9 (summation order differs)
+  * solved flow: max abs difference <= 1e-5 px/ms against the oracle running the
+    same trust-region algorithm
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def oparams(orc, p):
+    return orc.default_params(
+        image_w=p.image_w, image_h=p.image_h, patch_w=p.patch_w, patch_h=p.patch_h,
+        tv_weight=p.tv_weight, tv_huber=p.tv_huber, scale=p.scale, min_events=p.min_events,
+        loss=p.loss)
+
+
+def ctx_for(ebo, synth, config, **kw):
+    cfg = synth.CONFIGS[config]
+    args = dict(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE)
+    args.update(kw)
+    return ebo.Context(**args)
+
+
+def assert_close(a, b, rtol=RTOL, atol=1e-12):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 50000), (3, 40000)])
+def test_eval_value_and_jacobian(ebo, orc, synth, config, n_events):
+    ev, gt = synth.make_window(config, n_events=n_events)
+    with ctx_for(ebo, synth, config) as c:
+        c.set_window(ev)
+        rng = np.random.RandomState(config)
+        for flows in (np.zeros((c.P, 2)), gt * 0.5, rng.uniform(-1, 1, (c.P, 2))):
+            r, J = c.eval(flows)
+            ro, Jo, active, counts = orc.window_eval(ev, oparams(orc, c.params), flows)
+            for p in range(c.P):
+                n, a, _ = c.patch_info(p)
+                assert n == counts[p] and a == bool(active[p])
+            assert_close(r[0], ro)
+            assert_close(J[0], Jo, atol=1e-10)
+            r1, _ = c.eval(flows, want_jac=False)
+            assert_close(r1[0], ro)
+            assert np.all(r[0][active == 0] == 0.0)
+
+
+def test_eval_reference_times(ebo, orc, synth):
+    """Window and per-patch reference times (feature_detector.cpp:305-306,
+    contrast_functor.h:18-20) are the int32-truncated mid times."""
+    ev, _ = synth.make_window(2, n_events=20000)
+    with ctx_for(ebo, synth, 2) as c:
+        c.set_window(ev)
+        t, n = c.window_info()
+        assert n == len(ev)
+        assert t == orc.mid_timestamp(ev["t_us"][0], ev["t_us"][-1])
+        for p in (0, 9, 63):
+            x, y, w, h = c.patch_rect(p % c.npx, p // c.npx)
+            m = (ev["x"] >= x) & (ev["x"] < x + w) & (ev["y"] >= y) & (ev["y"] < y + h)
+            sub = ev[m]
+            cnt, _, tp = c.patch_info(p)
+            assert cnt == len(sub)
+            assert tp == orc.mid_timestamp(sub["t_us"][0], sub["t_us"][-1])
+
+
+def test_contrast_image_channels(ebo, orc, synth):
+    """The image of warped events itself (contrast_functor.h:38-88), all 3 Jet channels."""
+    ev, gt = synth.make_window(2, n_events=30000)
+    with ctx_for(ebo, synth, 2) as c:
+        c.set_window(ev)
+        for p in (0, 27, 63):  # interior, interior, remainder corner (30x26)
+            rect = c.patch_rect(p % c.npx, p // c.npx)
+            x, y, w, h = rect
+            m = (ev["x"] >= x) & (ev["x"] < x + w) & (ev["y"] >= y) & (ev["y"] < y + h)
+            for flow in ((0.0, 0.0), tuple(gt[p]), (-0.83, 0.41)):
+                img = c.contrast_image(p, flow, 3)
+                ref = orc.contrast_image(ev[m], rect, flow, 3)
+                assert img.shape == ref.shape
+                np.testing.assert_allclose(img, ref, rtol=1e-11, atol=1e-13)
+                img1 = c.contrast_image(p, flow, 1)
+                np.testing.assert_allclose(img1[0], ref[0], rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("tiles", ["1", "2", "3", "7"])
+def test_row_tiling_is_invisible(ebo, orc, synth, tiles, monkeypatch):
+    ev, gt = synth.make_window(0, n_events=15000)
+    monkeypatch.setenv("EBO_EVAL_TILES", tiles)
+    with ctx_for(ebo, synth, 0) as c:
+        c.set_window(ev)
+        r, J = c.eval(gt * 0.7)
+        ro, Jo, _, _ = orc.window_eval(ev, oparams(orc, c.params), gt * 0.7)
+        assert_close(r[0], ro)
+        assert_close(J[0], Jo, atol=1e-10)
+
+
+@pytest.mark.parametrize("block", ["64", "512", "1024"])
+def test_block_size_is_invisible(ebo, orc, synth, block, monkeypatch):
+    ev, gt = synth.make_window(0, n_events=15000)
+    monkeypatch.setenv("EBO_EVAL_BLOCK", block)
+    with ctx_for(ebo, synth, 0) as c:
+        c.set_window(ev)
+        r, J = c.eval(gt * 0.3)
+        ro, Jo, _, _ = orc.window_eval(ev, oparams(orc, c.params), gt * 0.3)
+        assert_close(r[0], ro)
+        assert_close(J[0], Jo, atol=1e-10)
+
+
+def test_out_of_window_penalty_branch(ebo, orc, synth):
+    """Huge flows: every event leaves the 3x patch window (contrast_functor.h:143-149)."""
+    ev, _ = synth.make_window(0, n_events=15000)
+    with ctx_for(ebo, synth, 0) as c:
+        c.set_window(ev)
+        flows = np.tile(np.array([[3.0e3, -7.0e3]]), (c.P, 1))
+        flows[5] = (1e9, 1e9)  # beyond int range: reference's int() is undefined, both skip
+        r, J = c.eval(flows)
+        ro, Jo, active, _ = orc.window_eval(ev, oparams(orc, c.params), flows)
+        assert_close(r[0], ro, rtol=1e-15)
+        assert_close(J[0], Jo, rtol=1e-15)
+        a = np.nonzero(active)[0][0]
+        assert r[0][a] == 1e3 * (1 + flows[a, 0] ** 2 + flows[a, 1] ** 2)
+
+
+def test_central_difference_gradient_mode(ebo, orc, synth):
+    ev, gt = synth.make_window(0, n_events=15000)
+    h = 1e-6
+    with ctx_for(ebo, synth, 0, grad=ebo.GRAD_CENTRAL, fd_step=h) as c:
+        c.set_window(ev)
+        flows = gt * 0.4
+        r, J = c.eval(flows)
+        prm = oparams(orc, c.params)
+        ro, Jo, active, _ = orc.window_eval(ev, prm, flows)
+        assert_close(r[0], ro)
+        num = np.zeros_like(Jo)
+        for k in range(2):
+            d = np.zeros_like(flows)
+            d[:, k] = h
+            rp, _, _, _ = orc.window_eval(ev, prm, flows + d, want_jac=False)
+            rm, _, _, _ = orc.window_eval(ev, prm, flows - d, want_jac=False)
+            num[:, k] = (rp - rm) / (2 * h)
+        # same formula on both sides: limited by cancellation in (r+ - r-), r ~ 1e3
+        np.testing.assert_allclose(J[0], num, rtol=0, atol=2e-6)
+        # and it approximates the analytic (Jet) Jacobian where no event changes bin
+        close = np.abs(J[0] - Jo) < 1e-3
+        assert close[active == 1].mean() > 0.9
+
+
+def test_edge_cases_sparse_and_stray(ebo, orc):
+    """Empty patches, patches at exactly min_events, events outside the sensor."""
+    rng = np.random.RandomState(3)
+    n = 400
+    x = rng.randint(0, 20, n)
+    y = rng.randint(0, 20, n)
+    t = np.sort(rng.randint(0, 20000, n)) + 5000
+    # patch (1,0): exactly 100 events (not > 100 => inactive); patch (2,0): 101 events
+    x = np.concatenate([x, rng.randint(20, 40, 100), rng.randint(40, 60, 101), [-3, 250, 7, 300]])
+    y = np.concatenate([y, rng.randint(0, 20, 100), rng.randint(0, 20, 101), [5, 5, -9, 200]])
+    t = np.concatenate([t, np.sort(rng.randint(0, 20000, 100)) + 5000,
+                        np.sort(rng.randint(0, 20000, 101)) + 5000, [6000, 7000, 8000, 9000]])
+    order = np.argsort(t, kind="stable")
+    ev = orc.make_events(x[order], y[order], t[order], np.where(rng.rand(len(t)) < 0.5, -1, 1))
+    with ebo.Context(loss=ebo.LOSS_VARIANCE) as c:
+        c.set_window(ev)
+        assert c.patch_info(0)[:2] == (400, True)
+        assert c.patch_info(1)[:2] == (100, False)
+        assert c.patch_info(2)[:2] == (101, True)
+        assert c.patch_info(50)[:2] == (0, False)
+        flows = rng.uniform(-0.5, 0.5, (c.P, 2))
+        r, J = c.eval(flows)
+        prm = oparams(orc, c.params)
+        ro, Jo, active, _ = orc.window_eval(ev, prm, flows)
+        assert active.sum() == 2
+        assert_close(r[0], ro)
+        assert_close(J[0], Jo, atol=1e-10)
+        # count images with strays: bit exact
+        assert np.array_equal(c.count_image(ebo.COUNT_INTEGRATED)[0], orc.integrate_events(ev, 240, 180))
+        assert np.array_equal(c.count_image(ebo.COUNT_WARPED, flows)[0], orc.final_count_image(ev, prm, flows))
+
+
+@pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 50000), (4, 300000)])
+def test_count_images_bit_exact(ebo, orc, synth, config, n_events):
+    ev, gt = synth.make_window(config, n_events=n_events)
+    with ctx_for(ebo, synth, config) as c:
+        c.set_window(ev)
+        prm = oparams(orc, c.params)
+        w, h = c.params.image_w, c.params.image_h
+        assert np.array_equal(c.count_image(ebo.COUNT_INTEGRATED)[0], orc.integrate_events(ev, w, h))
+        rng = np.random.RandomState(11)
+        for flows in (np.zeros((c.P, 2)), gt, rng.uniform(-3, 3, (c.P, 2))):
+            img = c.count_image(ebo.COUNT_WARPED, flows)[0]
+            ref = orc.final_count_image(ev, prm, flows)
+            assert np.array_equal(img, ref)
+            assert img.sum() <= len(ev)
+        field = rng.uniform(-2, 2, (h, w, 2)).astype(np.float32)
+        assert np.array_equal(c.count_image(ebo.COUNT_FIELD, field)[0],
+                              orc.compensate_events_field(ev, w, h, field))
+        # repeated calls start from a clean image
+        assert np.array_equal(c.count_image(ebo.COUNT_INTEGRATED)[0], orc.integrate_events(ev, w, h))
+
+
+def test_half_integer_rounding_on_device(ebo, orc):
+    """round() half away from zero (feature_detector.cpp:446-453) on exact .5 positions."""
+    # t_ref = 1000 us -> dt*scale = +1, 0, -1 ms; flows of +-0.5 and +-1.5 hit x.5 exactly
+    xs, ys, ts = [], [], []
+    for px in range(12):
+        for k, t in enumerate((0, 1000, 2000)):
+            xs.append(px * 20 + 5 + k)
+            ys.append(7)
+            ts.append(t)
+    order = np.argsort(ts, kind="stable")
+    ev = orc.make_events(np.array(xs)[order], np.array(ys)[order], np.array(ts)[order])
+    with ebo.Context(loss=ebo.LOSS_VARIANCE) as c:
+        c.set_window(ev)
+        flows = np.zeros((c.P, 2))
+        flows[:12, 0] = [0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5]
+        flows[:12, 1] = [-0.5, 0.5, -1.5, 1.5, 0.5, 0.5, -7.5, 7.5, 0.0, 0.0, 0.5, -0.5]
+        img = c.count_image(ebo.COUNT_WARPED, flows)[0]
+        assert np.array_equal(img, orc.final_count_image(ev, oparams(orc, c.params), flows))
+
+
+def test_batch_of_windows_equals_one_by_one(ebo, orc, synth):
+    ev, offsets, gt = synth.make_stream(0, 3, n_events=9000)
+    with ctx_for(ebo, synth, 0, max_windows=3) as c:
+        c.set_windows(ev, offsets)
+        flows = gt * 0.5
+        r, J = c.eval(flows)
+        img = c.count_image(ebo.COUNT_WARPED, flows)
+        prm = oparams(orc, c.params)
+        for w in range(3):
+            sub = ev[int(offsets[w]):int(offsets[w + 1])]
+            ro, Jo, _, _ = orc.window_eval(sub, prm, flows[w])
+            assert_close(r[w], ro)
+            assert_close(J[w], Jo, atol=1e-10)
+            assert np.array_equal(img[w], orc.final_count_image(sub, prm, flows[w]))
+            assert c.window_info(w)[0] == orc.mid_timestamp(sub["t_us"][0], sub["t_us"][-1])
+
+
+def _check_flows(f_gpu, f_ref, tol=1e-5):
+    err = np.abs(np.asarray(f_gpu) - np.asarray(f_ref)).max()
+    assert err <= tol, "max |flow_gpu - flow_oracle| = %.3e" % err
+
+
+@pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 50000)])
+def test_solve_independent_on_device(ebo, orc, synth, config, n_events):
+    """Per-patch LM entirely on the device vs the oracle's per-patch LM."""
+    ev, _ = synth.make_window(config, n_events=n_events)
+    with ctx_for(ebo, synth, config, tv_weight=0.0) as c:
+        c.set_window(ev)
+        flows, summ = c.solve(mode=ebo.SOLVE_INDEPENDENT)
+        prm = oparams(orc, c.params)
+        fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(mode=1), want_image=False)
+        _check_flows(flows[0], fo)
+        assert summ[0].num_evals_jac == so.num_evals_jac
+        assert summ[0].num_evals_cost == so.num_evals_cost
+        assert summ[0].iterations == so.iterations
+
+
+def test_solve_global_with_tv_matches_reference_problem(ebo, orc, synth):
+    """The reference's problem: all patches + TV terms in one LM (host) with batched
+    device evaluations (feature_detector.cpp:316-414)."""
+    ev, _ = synth.make_window(0, n_events=15000)
+    with ctx_for(ebo, synth, 0) as c:  # tv_weight 1e3, huber 10 (defaults)
+        c.set_window(ev)
+        flows, summ = c.solve(mode=ebo.SOLVE_GLOBAL)
+        prm = oparams(orc, c.params)
+        fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(mode=0), want_image=False)
+        _check_flows(flows[0], fo)
+        assert summ[0].iterations == so.iterations
+        assert summ[0].termination == so.termination
+        assert summ[0].final_cost == pytest.approx(so.final_cost, rel=1e-9)
+
+
+def test_solve_global_without_tv(ebo, orc, synth):
+    ev, _ = synth.make_window(0, n_events=12000)
+    with ctx_for(ebo, synth, 0, tv_weight=0.0) as c:
+        c.set_window(ev)
+        flows, summ = c.solve(mode=ebo.SOLVE_GLOBAL)
+        fo, _, so = orc.compensate_events_contrast(
+            ev, oparams(orc, c.params), orc.default_solver(mode=0), want_image=False)
+        _check_flows(flows[0], fo)
+        assert summ[0].iterations == so.iterations
+
+
+def test_compensate_events_contrast_one_call(ebo, orc, synth):
+    """R2 end to end: flows + final count image."""
+    ev, _ = synth.make_window(0, n_events=15000)
+    with ctx_for(ebo, synth, 0) as c:
+        flows, img, s = c.compensate_events_contrast(ev)
+        prm = oparams(orc, c.params)
+        fo, io, so = orc.compensate_events_contrast(ev, prm, orc.default_solver())
+        _check_flows(flows, fo)
+        # count image is bit exact for the SAME flows
+        assert np.array_equal(img, orc.final_count_image(ev, prm, flows))
+        # and with each side's own flows at most a few events land one pixel apart
+        assert np.abs(img - io).sum() <= 0.002 * len(ev)
+
+
+def test_patch_integrate_reference_known_answer(ebo, orc):
+    """patch_test.cpp:35-60 through the HIP path."""
+    xs = [7 + i // 7 for i in range(30)]
+    ys = [7 + i % 7 for i in range(30)]
+    sg = [1 if i % 2 == 0 else -1 for i in range(30)]
+    ev = orc.make_events(xs, ys, list(range(30)), sg)[::-1].copy()
+    with ebo.Context() as c:
+        imgs, cur, last = c.patch_integrate(ev, [0, 30], [(7.0, 7.0, 7.0, 7.0)])
+        nabla = imgs[0]
+        for i in range(30):
+            assert nabla[i % 7, i // 7] == (1.0 if i % 2 == 0 else -1.0)
+        assert cur[0] == 14 and last[0] == 0
+
+
+def test_patch_integrate_batched(ebo, orc):
+    rng = np.random.RandomState(5)
+    evs, offs, rects, trajs, mids = [], [0], [], [], []
+    for k in range(40):
+        n = rng.randint(1, 300)
+        cx, cy = rng.uniform(20, 200), rng.uniform(20, 150)
+        ext = 12
+        rect = (np.floor(cx) - ext + (0.5 if k % 3 == 0 else 0.0), np.floor(cy) - ext, 2 * ext + 1, 2 * ext + 1)
+        x = rng.randint(int(cx) - 16, int(cx) + 17, n)
+        y = rng.randint(int(cy) - 16, int(cy) + 17, n)
+        t = np.sort(rng.randint(0, 30000, n))[::-1] + 1000  # deque order: newest first
+        e = orc.make_events(x, y, t, np.where(rng.rand(n) < 0.5, -1, 1))
+        evs.append(e)
+        offs.append(offs[-1] + n)
+        rects.append(rect)
+        t_last = int(t[0]) - rng.randint(0, 2000)
+        t_pre = t_last - rng.randint(1000, 20000)
+        trajs.append((cx - rng.uniform(-3, 3), cy - rng.uniform(-3, 3), t_pre, cx, cy, t_last))
+        mids.append(orc.mid_timestamp(t[0], t[-1]) if k % 5 else t_last + 10 ** 7)
+    ev = np.concatenate(evs)
+    with ebo.Context() as c:
+        imgs, cur, last = c.patch_integrate(ev, offs, rects)
+        for k in range(40):
+            ref, rc, rl = orc.patch_integrate(evs[k], rects[k])
+            assert np.array_equal(imgs[k], ref)
+            assert cur[k] == rc and last[k] == rl
+        imgs, upd = c.patch_integrate_mc(ev, offs, rects, trajs, mids)
+        n_upd = 0
+        for k in range(40):
+            tr = trajs[k]
+            ref, ru = orc.patch_integrate_mc(evs[k], rects[k], tr[0:3], tr[3:6], mids[k])
+            assert bool(upd[k]) == ru
+            if ru:
+                n_upd += 1
+                assert np.array_equal(imgs[k], ref)
+            else:
+                assert not imgs[k].any()
+        assert 0 < n_upd < 40
+
+
+def test_error_behaviour(ebo, synth):
+    ev, _ = synth.make_window(0, n_events=2000)
+    with ebo.Context(loss=ebo.LOSS_VARIANCE) as c:
+        with pytest.raises(ebo.EboError) as ei:
+            c.n_windows = 1
+            c.eval(np.zeros((c.P, 2)))
+        assert ei.value.code == ebo.ERR_STATE
+        bad = ev.copy()
+        bad["x"][3] = 40000
+        with pytest.raises(ebo.EboError) as ei:
+            c.set_window(bad)
+        assert ei.value.code == ebo.ERR_RANGE
+        far = ev.copy()
+        far["t_us"][-1] += 1 << 33
+        with pytest.raises(ebo.EboError) as ei:
+            c.set_window(far)
+        assert ei.value.code == ebo.ERR_RANGE
+        with pytest.raises(ebo.EboError) as ei:
+            c.set_windows(ev, [0, 1000, 2000])  # capacity is one window
+        assert ei.value.code == ebo.ERR_ARG
+        c.set_window(ev)  # still usable after errors
+        r, _ = c.eval(np.zeros((c.P, 2)))
+        assert r.shape == (1, c.P)
