@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — Mevents/s warped+scored on MI355X (BASELINE.json's metric).
+
+A step = ONE batched objective evaluation (value + Jacobian of the variance-contrast
+objective, EBO_GRAD_JET) of every patch of `--windows` independent windows of the
+BASELINE config (default configs[1]: 240x180, 64 patches, 50k events/window), i.e.
+every event is warped by its patch's candidate flow, splatted and scored once per
+step.  Events, patch table and flows are resident in HBM before the timed region.
+Windows are independent problems (the reference re-initialises the flow to 0 for each
+window, feature_detector.cpp:318-326), so a stream is evaluated many windows at a time.
+
+N > 1 (torchrun, one rank per GPU): the windows (units) are sharded over ranks, each
+rank evaluates its own shard, and each step ends with ONE RCCL all-gather of the
+(r, J0, J1) triples — the exchange step of the replicated host solver.
+Per-GPU work is fixed as N grows => weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_EVENT_EVAL = 8  # packed {x:15, pol:1, y:15, dt:32}; SURVEY §8(d)
+
+
+def cpu_baseline(synth, cfg_idx, seconds_budget):
+    """The oracle (CPU port of the reference path, single thread like the reference)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    import orc
+    cfg = synth.CONFIGS[cfg_idx]
+    ev, gt = synth.make_window(cfg_idx)
+    prm = orc.default_params(image_w=cfg["image"][0], image_h=cfg["image"][1],
+                             patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=1, tv_weight=0.0)
+    flows = gt * 0.5
+    sec, n = orc.window_eval_timed(ev, prm, flows, True, 1)  # warm-up + calibration
+    reps = max(1, min(2000, int(seconds_budget / max(sec, 1e-6))))
+    sec, n = orc.window_eval_timed(ev, prm, flows, True, reps)
+    return {
+        "value": n / sec / 1e6, "unit": "Mevents/s", "cores": 1, "kind": "port",
+        "sample": "%d value+Jacobian evaluations of 1 window of %s (%d event-evaluations, %.1f s) "
+                  "by oracle/liboracle.so, single thread like the reference" % (reps, cfg["name"], n, sec),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE config index (2 = configs[1])")
+    ap.add_argument("--windows", type=int, default=256, help="independent windows per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+
+    ebo = importlib.import_module("event-based-odomety_amd")
+    synth = importlib.import_module("event-based-odomety_amd.synth")
+    cfg = synth.CONFIGS[args.config]
+
+    # ---- synthetic stream: `windows` windows per rank, distinct per rank ---------
+    Wn = args.windows
+    evs, gts = [], []
+    for w in range(Wn):
+        e, g = synth.make_window(args.config, window=rank * Wn + w)
+        evs.append(e)
+        gts.append(g)
+    offsets = np.zeros(Wn + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(e) for e in evs])
+    ev = np.concatenate(evs)
+    n_events = int(len(ev))
+    gt = np.stack(gts)
+    del evs
+
+    ctx = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
+                      patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,
+                      grad=ebo.GRAD_JET, tv_weight=0.0, max_events=n_events, max_windows=Wn)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_windows(ev, offsets)
+    P = ctx.P
+    active_events = sum(ctx.patch_info(p, w)[0] for w in range(Wn) for p in range(P) if ctx.patch_info(p, w)[1])
+
+    d_flows = torch.from_numpy(gt * 0.5).to("cuda")  # mid-solve candidate flows
+    d_out = torch.zeros((Wn * P, 3), dtype=torch.float64, device="cuda")
+    d_all = torch.zeros((world * Wn * P, 3), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        ctx.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([active_events], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_events = float(cnt.item())
+    else:
+        total_events = float(active_events)
+
+    # ---- dominant kernel: average launch duration by HIP events on ITS stream -----
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(args.steps):
+        ctx.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr())
+    e1.record(stream)
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    achieved = BYTES_PER_EVENT_EVAL * active_events / (kern_ms * 1e-3) / 1e9
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        # value-only evaluation (the cost-only evaluations of the LM loop)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(args.steps):
+            ctx.eval_device(d_flows.data_ptr(), 0, d_out.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        extras["value_only_mevents_per_s"] = active_events / (e0.elapsed_time(e1) / args.steps * 1e-3) / 1e6
+        # device-resident independent solve of every window (one launch)
+        d_sol = torch.zeros((Wn * P, 2), dtype=torch.float64, device="cuda")
+        d_stats = torch.zeros((Wn * P, 4), dtype=torch.int32, device="cuda")
+        opts = ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT)
+        ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        st = d_stats.cpu().numpy().reshape(Wn, P, 4)
+        ne = np.array([[ctx.patch_info(p, w)[0] for p in range(P)] for w in range(Wn)])
+        evals = (st[:, :, 1] + st[:, :, 2]) * ne
+        solve_ms = e0.elapsed_time(e1)
+        extras["solve_independent"] = {
+            "ms": solve_ms, "windows": Wn, "mevents_per_s": float(evals.sum()) / (solve_ms * 1e-3) / 1e6,
+            "mean_evals_per_patch": float((st[:, :, 1] + st[:, :, 2])[st[:, :, 2] > 0].mean()),
+        }
+        # integer count image (HBM-bound kernel): warped by the solved flows
+        d_img = torch.zeros((Wn, cfg["image"][1], cfg["image"][0]), dtype=torch.float64, device="cuda")
+        ctx.count_image_device(ebo.COUNT_WARPED, d_sol.data_ptr(), d_img.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(10):
+            ctx.count_image_device(ebo.COUNT_WARPED, d_sol.data_ptr(), d_img.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / 10
+        img_bytes = d_img.numel() * 8
+        extras["count_image_warped"] = {
+            "ms": cms, "mevents_per_s": n_events / (cms * 1e-3) / 1e6,
+            "gbs_algorithmic": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9,
+            "hbm_frac": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+        # single-window latency (one 50k-event window, one launch)
+        c1 = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
+                         patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,
+                         tv_weight=0.0, max_events=int(offsets[1]), max_windows=1)
+        c1.set_stream(stream.cuda_stream)
+        c1.set_window(ev[: int(offsets[1])])
+        f1 = d_flows[:1].contiguous()
+        o1 = torch.zeros((P, 3), dtype=torch.float64, device="cuda")
+        for _ in range(5):
+            c1.eval_device(f1.data_ptr(), 1, o1.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(200):
+            c1.eval_device(f1.data_ptr(), 1, o1.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        extras["single_window_eval_us"] = e0.elapsed_time(e1) / 200 * 1e3
+        c1.close()
+
+    if rank == 0:
+        base = cpu_baseline(synth, args.config, args.cpu_seconds) if world == 1 else None
+        value = total_events * args.steps / dt / 1e6
+        line = {
+            "metric": "Mevents/s warped+scored (value+Jacobian of the variance-contrast objective)",
+            "value": value, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "windows_per_gpu_per_step": Wn,
+                       "events_per_gpu_per_step": n_events, "scored_events_per_gpu_per_step": active_events,
+                       "patches_per_window": P, "loss": "variance", "grad": "jet",
+                       "parallelism": "windows sharded over %d GPU(s)%s" % (
+                           world, ", RCCL all-gather of (r,J) per step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_eval_variance<3>", "kernel_ms": kern_ms,
+                         "note": "algorithmic 8 B/event-evaluation; the kernel is bound by f64 LDS "
+                                 "atomics + f64 VALU, not HBM (DESIGN.md)"},
+            "cpu_baseline": base,
+            "extras": extras,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,8 +25,6 @@ namespace ebo
 {
 namespace
 {
-constexpr int kMaxWaves = 16;
-
 __device__ __forceinline__ void unpack(uint64_t rec, int& x, int& y, int& pos, int& dt)
 {
 	const uint32_t lo = static_cast<uint32_t>(rec);
@@ -263,7 +261,7 @@ __global__ void k_eval_variance(const uint64_t* __restrict__ events,
 		{
 			part[threadIdx.x] = 0.0;
 		}
-		if (fused && threadIdx.x < 3)
+		if (fused && !(u.flags & kUnitStray) && threadIdx.x < 3)
 		{
 			out[3 * u.flow_idx + threadIdx.x] = 0.0;
 		}
@@ -324,6 +322,10 @@ __global__ void k_combine_variance(const Unit* __restrict__ units, int nUnits,
 		return;
 	}
 	const Unit u = units[unit];
+	if (u.flags & kUnitStray)
+	{
+		return;  // stray buckets carry no objective and own no output slot
+	}
 	double res[5] = {0, 0, 0, 0, 0};
 	double j0 = 0.0, j1 = 0.0;
 	if (u.flags & kUnitActive)
@@ -656,7 +658,7 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 			}
 		}
 	}
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0 && !(u.flags & kUnitStray))
 	{
 		flowsOut[2 * u.flow_idx] = best0;
 		flowsOut[2 * u.flow_idx + 1] = best1;

@@ -146,6 +146,11 @@ int orc_window_eval(const orc_event* ev, size_t n, const orc_params* p,
 					const double* flows, double* r, double* jac,
 					int32_t* active, int32_t* counts);
 
+/* cpu_baseline timing: bucket once, then `reps` batched evaluations, steady clock. */
+int orc_window_eval_timed(const orc_event* ev, size_t n, const orc_params* p,
+						  const double* flows, int want_jac, int reps,
+						  double* seconds, uint64_t* event_evals);
+
 /* FeatureDetector::compensateEventsContrast (feature_detector.cpp:298-464):
  * flows [P][2] out, image [image_h][image_w] out (may be NULL). */
 int orc_compensate_events_contrast(const orc_event* ev, size_t n,

@@ -9,6 +9,7 @@
 #include "ebo_oracle.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1278,6 +1279,44 @@ int orc_window_eval(const orc_event* ev, size_t n, const orc_params* p,
 					  p->k, p->loss, flows + 2 * i, &r[i], jac ? jac + 2 * i : nullptr);
 		}
 	}
+	return 0;
+}
+
+// Timing helper for bench.py's cpu_baseline: buckets once (as one solve does),
+// then times `reps` batched evaluations (every active patch, value + Jacobian when
+// want_jac) with a steady clock.  Single thread, like the reference.
+int orc_window_eval_timed(const orc_event* ev, size_t n, const orc_params* p,
+						  const double* flows, int want_jac, int reps,
+						  double* seconds, uint64_t* event_evals)
+{
+	if (!ev || !p || !flows || !seconds || !event_evals || reps <= 0)
+	{
+		return -1;
+	}
+	Window w;
+	buildWindow(ev, n, *p, w);
+	const int P = w.g.npx * w.g.npy;
+	uint64_t cnt = 0;
+	volatile double sink = 0.0;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int rep = 0; rep < reps; ++rep)
+	{
+		for (int i = 0; i < P; ++i)
+		{
+			if (!patchActive(w, i))
+			{
+				continue;
+			}
+			double r, j[2];
+			evalPatch(w.bucket[i].data(), w.bucket[i].size(), w.rects[i], p->scale, p->k,
+					  p->loss, flows + 2 * i, &r, want_jac ? j : nullptr);
+			sink = sink + r;
+			cnt += w.bucket[i].size();
+		}
+	}
+	const auto t1 = std::chrono::steady_clock::now();
+	*seconds = std::chrono::duration<double>(t1 - t0).count();
+	*event_evals = cnt;
 	return 0;
 }
 

@@ -203,6 +203,19 @@ def window_eval(ev, prm, flows, want_jac=True):
     return r, (J if want_jac else None), active, counts
 
 
+def window_eval_timed(ev, prm, flows, want_jac=True, reps=1):
+    """(seconds, event_evaluations) of `reps` batched evaluations on one core."""
+    ev, p = _evp(ev)
+    flows = np.ascontiguousarray(flows, dtype=np.float64)
+    sec = C.c_double()
+    cnt = C.c_uint64()
+    rc = lib().orc_window_eval_timed(
+        p, C.c_size_t(len(ev)), C.byref(prm), _dp(flows), int(bool(want_jac)), int(reps),
+        C.byref(sec), C.byref(cnt))
+    assert rc == 0
+    return sec.value, cnt.value
+
+
 def compensate_events_contrast(ev, prm, opts=None, want_image=True):
     ev, p = _evp(ev)
     opts = opts or default_solver()
