@@ -101,6 +101,17 @@ EvalConsts make_consts(const ebo_ctx* c)
 	k.norm = 1.0 / ((2 * M_PI) * (sig * sig));
 	k.hs = -0.5 / (sig * sig);
 	k.inv_sigsq = 1.0 / (sig * sig);
+	k.ck1 = std::exp(k.hs * 1.0);
+	k.ck2 = std::exp(k.hs * 4.0);
+	k.ck3 = std::exp(k.hs * 9.0);
+	// fixed-point grid of the value image: a tap is < norm; choose k with norm < 2^(k-1)
+	int kexp = 0;
+	while (k.norm >= std::ldexp(0.5, kexp))
+	{
+		++kexp;
+	}
+	k.fix_bias = std::ldexp(1.5, kexp);
+	k.fix_scale = std::ldexp(1.0, kexp - 52);
 	k.image_w = c->prm.image_w;
 	k.image_h = c->prm.image_h;
 	k.patch_w = c->prm.patch_w;
@@ -224,6 +235,32 @@ int ensure_scratch(ebo_ctx* c, size_t bytes)
 // Evaluation geometry.  tiles: row tiles per unit (parallel workgroups).  More
 // tiles = more workgroups and less LDS each; the events of a unit are re-read
 // (from L2) by each of its tiles.  EBO_EVAL_TILES / EBO_EVAL_BLOCK override.
+// impl 1/2: the image is the bounding box of the warped events; one workgroup owns
+// `cap` pixels of LDS (default 32 KiB => 5 workgroups per CU) and walks larger boxes
+// in sequential sub-bands.  A full canvas row must fit.
+int image_capacity(ebo_ctx* c, int& capDoubles, size_t& lds)
+{
+	const size_t headerBytes = 160 * sizeof(double);
+	size_t kb = env_size("EBO_LDS_KB", 32);
+	size_t bytes = std::min<size_t>(std::max<size_t>(kb, 4) * 1024, kLdsBudget);
+	// keep at least 24 rows of the widest canvas where that fits
+	const size_t want = static_cast<size_t>(24) * 3 * c->max_rw * sizeof(double) + headerBytes;
+	bytes = std::min(std::max(bytes, want), kLdsBudget);
+	if (bytes < headerBytes + static_cast<size_t>(3) * c->max_rw * sizeof(double))
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "patch too wide: one canvas row does not fit LDS");
+	}
+	capDoubles = static_cast<int>((bytes - headerBytes) / sizeof(double));
+	lds = bytes;
+	return EBO_OK;
+}
+
+int eval_impl()
+{
+	const int v = static_cast<int>(env_size("EBO_EVAL_IMPL", 2));
+	return (v < 0 || v > 2) ? 2 : v;
+}
+
 int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
 {
 	const size_t budget = env_size("EBO_LDS_BUDGET", kLdsBudget);
@@ -275,7 +312,30 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	L.flow_sets = central ? 5 : 1;
 	L.channels = (want_jac && !central) ? 3 : 1;
 	L.fd_step = central ? c->prm.fd_step : 0.0;
-	int rc = eval_geometry(c, L.channels, L.tiles, L.block, L.lds_bytes);
+	L.impl = eval_impl();
+	L.cap_doubles = 0;
+	int rc;
+	if (L.impl == 0)
+	{
+		rc = eval_geometry(c, L.channels, L.tiles, L.block, L.lds_bytes);
+	}
+	else
+	{
+		rc = image_capacity(c, L.cap_doubles, L.lds_bytes);
+		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", 256));
+		if (L.block < 64 || L.block > 1024 || (L.block & 63))
+		{
+			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,1024]");
+		}
+		// row bands per unit: one unless there are too few units to fill 256 CUs
+		int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
+		if (t <= 0)
+		{
+			const int nUnits = std::max(1, c->n_windows * c->P);
+			t = std::min(8, std::max(1, (1024 + nUnits - 1) / nUnits));
+		}
+		L.tiles = t;
+	}
 	if (rc)
 	{
 		return rc;
@@ -372,18 +432,17 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
-	const size_t budget = env_size("EBO_LDS_BUDGET", kLdsBudget);
-	L.tiles3 = min_tiles(3, c->max_rw, c->max_rh, budget);
-	L.tiles1 = min_tiles(1, c->max_rw, c->max_rh, budget);
-	if (L.tiles3 < 0 || L.tiles1 < 0)
+	L.impl = eval_impl() == 1 ? 1 : 2;
+	int rc = image_capacity(c, L.cap_doubles, L.lds_bytes);
+	if (rc)
 	{
-		return c->fail(EBO_ERR_UNSUPPORTED, "patch too wide for LDS row tiling");
+		return rc;
 	}
-	L.tiles3 = std::max<int>(L.tiles3, static_cast<int>(env_size("EBO_SOLVE_TILES3", 0)));
-	L.tiles1 = std::max<int>(L.tiles1, static_cast<int>(env_size("EBO_SOLVE_TILES1", 0)));
 	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", 256));
-	L.lds_bytes = std::max(lds_for(3, L.tiles3, c->max_rw, c->max_rh),
-						   lds_for(1, L.tiles1, c->max_rw, c->max_rh));
+	if (L.block < 64 || L.block > 512 || (L.block & 63))
+	{
+		return c->fail(EBO_ERR_ARG, "EBO_SOLVE_BLOCK must be a multiple of 64 in [64,512]");
+	}
 	L.d_flows_out = d_flows_out;
 	L.d_stats = d_stats;
 	L.c = make_consts(c);

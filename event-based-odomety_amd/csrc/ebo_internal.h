@@ -51,6 +51,9 @@ struct EvalConsts
 	double norm;          // 1 / (2 pi sigma^2)
 	double hs;            // -0.5 / sigma^2
 	double inv_sigsq;     // 1 / sigma^2
+	double ck1, ck2, ck3; // exp(hs * k^2), k = 1..3 (factored 1-D Gaussian taps)
+	double fix_bias;      // 1.5 * 2^k: adding it aligns a tap value to the fixed-point grid
+	double fix_scale;     // 2^(k-52): value of one fixed-point unit
 	int32_t image_w, image_h;
 	int32_t patch_w, patch_h;
 	int32_t npx, npy;
@@ -83,6 +86,10 @@ struct EvalLaunch
 	int channels;          // 1 or 3
 	int tiles;             // row tiles per unit
 	int block;             // threads per workgroup
+	int impl;              // 0: 3-channel f64 atomics on the full canvas (first version)
+	                       // 1: scatter value / gather derivatives, f64 atomics
+	                       // 2: same with exact fixed-point (u64) accumulation
+	int cap_doubles;       // impl 1/2: image capacity of one workgroup's LDS, in pixels
 	size_t lds_bytes;
 	double* d_partials;    // [flow sets][n_units][tiles][kPartialStride]
 	double* d_out;         // [n_flow][3]
@@ -97,7 +104,8 @@ struct SolveLaunch
 	const uint64_t* d_events;
 	const Unit* d_units;
 	int n_units;
-	int tiles3, tiles1;  // sequential row tiles for the 3- and 1-channel image
+	int impl;            // 1 or 2 (see EvalLaunch)
+	int cap_doubles;
 	int block;
 	size_t lds_bytes;
 	double* d_flows_out; // [n_flow][2]

@@ -239,8 +239,372 @@ __device__ __forceinline__ void fd_offset(int set, double h, double& m0, double&
 	if (set == 4) m1 -= h;
 }
 
+// ===========================================================================
+// Second-generation evaluation (impl 1 / 2): scatter the VALUE, gather the
+// DERIVATIVES.
+//
+// The Jacobian of the variance objective needs only  D1k = sum_px dI_k  and
+// D2k = sum_px I dI_k  over the touched pixels (every touched pixel has I > 0:
+// Gaussian taps are strictly positive).  With dI_k(px) = sum_e d_k(e, px):
+//     D1k = sum_e sum_taps d_k(e,tap)                    -- no image at all
+//     D2k = sum_e sum_taps I(px(e,tap)) d_k(e,tap)       -- a READ of the value image
+// i.e. forward-mode Jets are re-associated into "value image, then one gather
+// pass": 49 LDS atomics + 49 LDS reads per event instead of 147 atomics, and a
+// third of the LDS.  Mathematically identical to the Jet result.
+//
+// Further: (a) the image covers only the bounding box of the warped events inside
+// the 3W x 3H canvas (the canvas is mostly empty), split in `tiles` row bands
+// (parallel workgroups) and, if a band exceeds the workgroup's LDS, in sequential
+// sub-bands; (b) impl 2 accumulates taps as exact 64-bit fixed point
+// (ds_add_u64): tap values are < 0.5, so (v + 1.5) has ulp 2^-52 and its mantissa
+// IS the fixed-point number -- one v_add_f64 + a 64-bit integer subtract.  Integer
+// adds commute: the image, and with the fixed reduction order the whole result,
+// is bit-reproducible from run to run; it is also faster than ds_add_f64 under
+// same-address conflicts (tools/microbench/lds_atomics.hip); (c) the 7 taps of
+// an axis come from 3 exps:  exp(hs (k-f)^2) = exp(hs k^2) exp(hs f^2) exp(f/s^2)^k.
+// ===========================================================================
+constexpr int kRedDoubles = 128;  // 16 waves x 8
+constexpr int kLdsHeader = 160;   // red[128] + 32 doubles of int scratch
+
+__device__ __forceinline__ bool warp_event(uint64_t rec, int rx, int ry, int rw, int rh,
+											double m0, double m1, const EvalConsts& c, int& pxc,
+											int& pyc, double& fx, double& fy, double& tau)
+{
+	int x, y, pos, dt;
+	unpack(rec, x, y, pos, dt);
+	tau = static_cast<double>(dt) * c.scale;
+	const double cx = static_cast<double>(x) + tau * m0;  // not fused: -ffp-contract=off
+	const double cy = static_cast<double>(y) + tau * m1;
+	if (!convertible(cx) || !convertible(cy))
+	{
+		return false;
+	}
+	const int bx = static_cast<int>(cx);  // truncation (contrast_functor.h:59,63)
+	const int by = static_cast<int>(cy);
+	pxc = bx - rx + rw;  // canvas column / row of the centre tap
+	pyc = by - ry + rh;
+	if (pxc + 3 < 0 || pxc - 3 >= 3 * rw || pyc + 3 < 0 || pyc - 3 >= 3 * rh)
+	{
+		return false;
+	}
+	fx = cx - static_cast<double>(bx);  // exact
+	fy = cy - static_cast<double>(by);
+	return true;
+}
+
+// w[k] = pre * exp(hs (k-3-f)^2), k = 0..6, from three exps.
+__device__ __forceinline__ void axis_taps(double f, double pre, const EvalConsts& c, double (&w)[7])
+{
+	const double e0 = pre * exp(c.hs * (f * f));
+	const double a = f * c.inv_sigsq;
+	const double p = exp(a);
+	const double q = exp(-a);
+	const double p2 = p * p, q2 = q * q;
+	const double e1 = c.ck1 * e0, e2 = c.ck2 * e0, e3 = c.ck3 * e0;
+	w[3] = e0;
+	w[4] = e1 * p;
+	w[5] = e2 * p2;
+	w[6] = e3 * (p2 * p);
+	w[2] = e1 * q;
+	w[1] = e2 * q2;
+	w[0] = e3 * (q2 * q);
+}
+
+__device__ __forceinline__ void block_minmax(int& xmin, int& xmax, int& ymin, int& ymax, int* ired)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		xmin = min(xmin, __shfl_down(xmin, off, 64));
+		xmax = max(xmax, __shfl_down(xmax, off, 64));
+		ymin = min(ymin, __shfl_down(ymin, off, 64));
+		ymax = max(ymax, __shfl_down(ymax, off, 64));
+	}
+	__syncthreads();
+	if (lane == 0)
+	{
+		ired[wave * 4 + 0] = xmin;
+		ired[wave * 4 + 1] = xmax;
+		ired[wave * 4 + 2] = ymin;
+		ired[wave * 4 + 3] = ymax;
+	}
+	__syncthreads();
+	xmin = ired[0];
+	xmax = ired[1];
+	ymin = ired[2];
+	ymax = ired[3];
+	for (int w = 1; w < nw; ++w)
+	{
+		xmin = min(xmin, ired[w * 4 + 0]);
+		xmax = max(xmax, ired[w * 4 + 1]);
+		ymin = min(ymin, ired[w * 4 + 2]);
+		ymax = max(ymax, ired[w * 4 + 3]);
+	}
+}
+
+// The seven sums of one (unit, row band) at flow (m0, m1); every thread returns
+// the same totals.  lds: [red 128][int scratch 32][image capDoubles].
+template <bool FIXED>
+__device__ __forceinline__ void eval_unit2(const uint64_t* __restrict__ ev, const Unit& u, double m0,
+											double m1, bool wantJac, int tile, int tiles,
+											int capDoubles, const EvalConsts& c, double* lds,
+											double (&S)[7])
+{
+	double* red = lds;
+	int* ired = reinterpret_cast<int*>(lds + kRedDoubles);
+	double* img = lds + kLdsHeader;
+	unsigned long long* imgq = reinterpret_cast<unsigned long long*>(img);
+	const int rx = u.rx, ry = u.ry, rw = u.rw, rh = u.rh;
+	const int W3 = 3 * rw, H3 = 3 * rh;
+	const uint32_t nEv = u.n_ev;
+#pragma unroll
+	for (int k = 0; k < 7; ++k)
+	{
+		S[k] = 0.0;
+	}
+
+	// ---- pass A: bounding box of the centre taps that touch the canvas ----
+	int xmin = 0x7fffffff, xmax = -0x7fffffff, ymin = 0x7fffffff, ymax = -0x7fffffff;
+	for (uint32_t e = threadIdx.x; e < nEv; e += blockDim.x)
+	{
+		int pxc, pyc;
+		double fx, fy, tau;
+		if (warp_event(ev[e], rx, ry, rw, rh, m0, m1, c, pxc, pyc, fx, fy, tau))
+		{
+			xmin = min(xmin, pxc);
+			xmax = max(xmax, pxc);
+			ymin = min(ymin, pyc);
+			ymax = max(ymax, pyc);
+		}
+	}
+	block_minmax(xmin, xmax, ymin, ymax, ired);
+	if (xmin > xmax)
+	{
+		return;  // nothing lands in the window: all sums 0 => penalty branch
+	}
+	const int x0 = max(xmin - 3, 0), x1 = min(xmax + 3, W3 - 1);
+	const int y0 = max(ymin - 3, 0), y1 = min(ymax + 3, H3 - 1);
+	const int cols = x1 - x0 + 1;
+	const int rowsAll = y1 - y0 + 1;
+	const int R = (rowsAll + tiles - 1) / tiles;
+	const int ty0 = y0 + tile * R;
+	const int ty1 = min(ty0 + R, y1 + 1);
+	const int maxRows = max(capDoubles / cols, 1);
+	const unsigned long long biasBits = static_cast<unsigned long long>(__double_as_longlong(c.fix_bias));
+
+	for (int sy0 = ty0; sy0 < ty1; sy0 += maxRows)
+	{
+		const int srows = min(maxRows, ty1 - sy0);
+		const int npx = srows * cols;
+		__syncthreads();
+		for (int i = threadIdx.x; i < npx; i += blockDim.x)
+		{
+			img[i] = 0.0;  // also the all-zero bit pattern of the fixed-point image
+		}
+		__syncthreads();
+
+		// ---- pass B: scatter the value taps ----
+		for (uint32_t e = threadIdx.x; e < nEv; e += blockDim.x)
+		{
+			int pxc, pyc;
+			double fx, fy, tau;
+			if (!warp_event(ev[e], rx, ry, rw, rh, m0, m1, c, pxc, pyc, fx, fy, tau))
+			{
+				continue;
+			}
+			const int rowLo = pyc - 3 - sy0;  // band-local row of tap j = 0
+			if (rowLo + 6 < 0 || rowLo >= srows)
+			{
+				continue;
+			}
+			double wx[7], wy[7];
+			axis_taps(fx, c.norm, c, wx);
+			axis_taps(fy, 1.0, c, wy);
+			const int colLo = pxc - 3 - x0;
+#pragma unroll
+			for (int j = 0; j < 7; ++j)
+			{
+				const int row = rowLo + j;
+				if (row < 0 || row >= srows)
+				{
+					continue;
+				}
+				const int base = row * cols + colLo;
+#pragma unroll
+				for (int i = 0; i < 7; ++i)
+				{
+					const int col = colLo + i;
+					if (col < 0 || col >= cols)
+					{
+						continue;
+					}
+					const double v = wx[i] * wy[j];
+					if (FIXED)
+					{
+						const unsigned long long q =
+							static_cast<unsigned long long>(__double_as_longlong(v + c.fix_bias)) - biasBits;
+						atomicAdd(&imgq[base + i], q);
+					}
+					else
+					{
+						atomicAdd(&img[base + i], v);
+					}
+				}
+			}
+		}
+		__syncthreads();
+
+		// ---- pass C: pixel sums (contrast_functor.h:111-121, :129-139) ----
+		for (int p = threadIdx.x; p < npx; p += blockDim.x)
+		{
+			double I;
+			if (FIXED)
+			{
+				const unsigned long long q = imgq[p];
+				I = static_cast<double>(q) * c.fix_scale;
+				img[p] = I;
+			}
+			else
+			{
+				I = img[p];
+			}
+			if (I > 0.0)
+			{
+				S[0] += I;
+				S[1] = fma(I, I, S[1]);
+				S[2] += 1.0;
+			}
+		}
+		if (!wantJac)
+		{
+			continue;
+		}
+		__syncthreads();
+
+		// ---- pass D: gather the derivative sums ----
+		for (uint32_t e = threadIdx.x; e < nEv; e += blockDim.x)
+		{
+			int pxc, pyc;
+			double fx, fy, tau;
+			if (!warp_event(ev[e], rx, ry, rw, rh, m0, m1, c, pxc, pyc, fx, fy, tau))
+			{
+				continue;
+			}
+			const int rowLo = pyc - 3 - sy0;
+			if (rowLo + 6 < 0 || rowLo >= srows)
+			{
+				continue;
+			}
+			double wx[7], wy[7];
+			axis_taps(fx, c.norm, c, wx);
+			axis_taps(fy, 1.0, c, wy);
+			const int colLo = pxc - 3 - x0;
+			const double g = tau * c.inv_sigsq;
+			// columns outside the canvas carry no tap: zero weight, clamped address
+			double ax[7];
+			int ci[7];
+			double sumW = 0.0, sumA = 0.0;
+#pragma unroll
+			for (int i = 0; i < 7; ++i)
+			{
+				const int col = colLo + i;
+				const bool ok = col >= 0 && col < cols;
+				wx[i] = ok ? wx[i] : 0.0;
+				ax[i] = wx[i] * (g * (static_cast<double>(i - 3) - fx));
+				ci[i] = min(max(col, 0), cols - 1);
+				sumW += wx[i];
+				sumA += ax[i];
+			}
+			double sumWy = 0.0, sumAy = 0.0, d2a = 0.0, d2b = 0.0;
+#pragma unroll
+			for (int j = 0; j < 7; ++j)
+			{
+				const int row = rowLo + j;
+				if (row < 0 || row >= srows)
+				{
+					continue;
+				}
+				const double ay = wy[j] * (g * (static_cast<double>(j - 3) - fy));
+				sumWy += wy[j];
+				sumAy += ay;
+				const double* rowp = img + row * cols;
+				double ra = 0.0, rb = 0.0;
+#pragma unroll
+				for (int i = 0; i < 7; ++i)
+				{
+					const double I = rowp[ci[i]];
+					ra = fma(ax[i], I, ra);
+					rb = fma(wx[i], I, rb);
+				}
+				d2a = fma(wy[j], ra, d2a);
+				d2b = fma(ay, rb, d2b);
+			}
+			S[3] = fma(sumA, sumWy, S[3]);
+			S[4] = fma(sumW, sumAy, S[4]);
+			S[5] += d2a;
+			S[6] += d2b;
+		}
+	}
+	block_sum<7>(S, red);
+}
+
+template <bool FIXED>
+__global__ void __launch_bounds__(512) k_eval2(const uint64_t* __restrict__ events, const Unit* __restrict__ units,
+						const double* __restrict__ flows, int tiles, int wantJac, int capDoubles,
+						double fdStep, double* __restrict__ partials, double* __restrict__ out,
+						EvalConsts c)
+{
+	extern __shared__ double lds[];
+	const int unit = blockIdx.x / tiles;
+	const int tile = blockIdx.x - unit * tiles;
+	const int set = blockIdx.y;
+	const Unit u = units[unit];
+	double* part = partials + ((static_cast<size_t>(set) * gridDim.x) + blockIdx.x) * kPartialStride;
+	const bool fused = (tiles == 1 && gridDim.y == 1);
+	if (!(u.flags & kUnitActive))
+	{
+		if (!fused && threadIdx.x < 7)
+		{
+			part[threadIdx.x] = 0.0;
+		}
+		if (fused && !(u.flags & kUnitStray) && threadIdx.x < 3)
+		{
+			out[3 * u.flow_idx + threadIdx.x] = 0.0;
+		}
+		return;
+	}
+	double m0 = flows[2 * u.flow_idx];
+	double m1 = flows[2 * u.flow_idx + 1];
+	fd_offset(set, fdStep, m0, m1);
+	double S[7];
+	eval_unit2<FIXED>(events + u.ev_off, u, m0, m1, wantJac != 0, tile, tiles, capDoubles, c, lds, S);
+	if (threadIdx.x == 0)
+	{
+		if (fused)
+		{
+			double r, j0 = 0.0, j1 = 0.0;
+			variance_from_sums(S, wantJac != 0, m0, m1, c.max_res, r, j0, j1);
+			out[3 * u.flow_idx + 0] = r;
+			out[3 * u.flow_idx + 1] = j0;
+			out[3 * u.flow_idx + 2] = j1;
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < 7; ++k)
+			{
+				part[k] = S[k];
+			}
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------
-// Batched objective evaluation (R1): workgroup = (flow set, unit, row tile).
+// First-generation batched evaluation (impl 0, kept for A/B): full 3W x 3H canvas,
+// one f64 atomic per tap and channel.  Workgroup = (flow set, unit, row tile).
 // ---------------------------------------------------------------------------
 template <int C>
 __global__ void k_eval_variance(const uint64_t* __restrict__ events,
@@ -412,48 +776,22 @@ __global__ void k_dump_image(const uint64_t* __restrict__ events, const Unit* __
 // feature_detector.cpp:401-410.  Every thread carries the (uniform) solver state;
 // the objective is evaluated cooperatively.  No host round trips.
 // ---------------------------------------------------------------------------
-template <int C>
+template <bool FIXED>
 __device__ __forceinline__ void eval_unit(const uint64_t* __restrict__ ev, const Unit& u,
-										   double m0, double m1, int tiles, const EvalConsts& c,
-										   double* lds, double& r, double& j0, double& j1)
+										   double m0, double m1, bool wantJac, int capDoubles,
+										   const EvalConsts& c, double* lds, double& r, double& j0,
+										   double& j1)
 {
-	const int W3 = 3 * u.rw;
-	const int H3 = 3 * u.rh;
-	const int R = (H3 + tiles - 1) / tiles;
-	double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-	for (int tile = 0; tile < tiles; ++tile)
-	{
-		const int r0 = tile * R;
-		const int rows = min(R, H3 - r0);
-		if (rows <= 0)
-		{
-			break;
-		}
-		const int plane = rows * W3;
-		double* red = lds + C * R * W3;
-		__syncthreads();
-		for (int i = threadIdx.x; i < C * plane; i += blockDim.x)
-		{
-			lds[i] = 0.0;
-		}
-		__syncthreads();
-		splat_rows<C>(ev, u.n_ev, u.rx, u.ry, u.rw, u.rh, r0, rows, m0, m1, c, lds, plane);
-		__syncthreads();
-		double S[7];
-		tile_sums<C>(lds, plane, red, S);
-#pragma unroll
-		for (int k = 0; k < 7; ++k)
-		{
-			acc[k] += S[k];
-		}
-	}
+	double S[7];
+	eval_unit2<FIXED>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
 	j0 = 0.0;
 	j1 = 0.0;
-	variance_from_sums(acc, C == 3, m0, m1, c.max_res, r, j0, j1);
+	variance_from_sums(S, wantJac, m0, m1, c.max_res, r, j0, j1);
 }
 
+template <bool FIXED>
 __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __restrict__ events,
-									const Unit* __restrict__ units, int tiles3, int tiles1,
+									const Unit* __restrict__ units, int capDoubles,
 									double* __restrict__ flowsOut, int32_t* __restrict__ stats,
 									EvalConsts c, SolveConsts o)
 {
@@ -467,7 +805,7 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 	{
 		double x0 = 0.0, x1 = 0.0;  // feature_detector.cpp:318-326
 		double f, J0, J1;
-		eval_unit<3>(ev, u, x0, x1, tiles3, c, lds, f, J0, J1);
+		eval_unit<FIXED>(ev, u, x0, x1, true, capDoubles, c, lds, f, J0, J1);
 		evalsJac++;
 		double xCost = 0.5 * f * f;
 		termination = 1;
@@ -577,7 +915,7 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 				const double c0 = x0 + s0 * sc0;
 				const double c1 = x1 + s1 * sc1;
 				double fc, t0, t1;
-				eval_unit<1>(ev, u, c0, c1, tiles1, c, lds, fc, t0, t1);
+				eval_unit<FIXED>(ev, u, c0, c1, false, capDoubles, c, lds, fc, t0, t1);
 				evalsCost++;
 				double candCost = 0.5 * fc * fc;
 				if (!isfinite(candCost))
@@ -605,7 +943,7 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 					x0 = c0;
 					x1 = c1;
 					xNorm = sqrt(x0 * x0 + x1 * x1);
-					eval_unit<3>(ev, u, x0, x1, tiles3, c, lds, f, J0, J1);
+					eval_unit<FIXED>(ev, u, x0, x1, true, capDoubles, c, lds, f, J0, J1);
 					evalsJac++;
 					xCost = 0.5 * f * f;
 					if (!isfinite(xCost))
@@ -847,13 +1185,27 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		return 0;
 	}
 	const dim3 grid(L.n_units * L.tiles, L.flow_sets);
-	auto kern = (L.channels == 3) ? k_eval_variance<3> : k_eval_variance<1>;
-	if (allow_big_lds(kern, L.lds_bytes))
+	if (L.impl == 0)
 	{
-		return -2;
+		auto kern = (L.channels == 3) ? k_eval_variance<3> : k_eval_variance<1>;
+		if (allow_big_lds(kern, L.lds_bytes))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
+						   L.d_flows, L.tiles, L.fd_step, L.d_partials, L.d_out, L.c);
 	}
-	hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
-					   L.d_flows, L.tiles, L.fd_step, L.d_partials, L.d_out, L.c);
+	else
+	{
+		auto kern = (L.impl == 2) ? k_eval2<true> : k_eval2<false>;
+		if (allow_big_lds(kern, L.lds_bytes))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
+						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
+						   L.d_partials, L.d_out, L.c);
+	}
 	if (check_launch())
 	{
 		return -2;
@@ -887,13 +1239,13 @@ int launch_solve_independent(const SolveLaunch& L, void* stream)
 	{
 		return 0;
 	}
-	if (allow_big_lds(k_solve_independent, L.lds_bytes))
+	auto kern = (L.impl == 2) ? k_solve_independent<true> : k_solve_independent<false>;
+	if (allow_big_lds(kern, L.lds_bytes))
 	{
 		return -2;
 	}
-	hipLaunchKernelGGL(k_solve_independent, dim3(L.n_units), dim3(L.block), L.lds_bytes, s,
-					   L.d_events, L.d_units, L.tiles3, L.tiles1, L.d_flows_out, L.d_stats, L.c,
-					   L.s);
+	hipLaunchKernelGGL(kern, dim3(L.n_units), dim3(L.block), L.lds_bytes, s, L.d_events,
+					   L.d_units, L.cap_doubles, L.d_flows_out, L.d_stats, L.c, L.s);
 	return check_launch();
 }
 

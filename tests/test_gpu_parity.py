@@ -247,19 +247,55 @@ def _check_flows(f_gpu, f_ref, tol=1e-5):
     assert err <= tol, "max |flow_gpu - flow_oracle| = %.3e" % err
 
 
+# The TV-free solve is chaotic in the reference's own formulation (residual
+# 1000 - var makes every Gauss-Newton step ~1000/|J|): a 1-ulp change of
+# compensateScale moves the CPU path's OWN answer by 0.2 px/ms after 50 iterations
+# (tests/test_oracle_golden.py::test_tv_free_solve_is_chaotic_on_the_cpu_alone).  The
+# 1e-5 bar is therefore checked (a) on the reference's configuration (TV on, full 50
+# iterations) and (b) on TV-free solves up to the iteration count where the CPU path's
+# own 1-ulp sensitivity is still below the bar; past that, on invariants.
 @pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 50000)])
-def test_solve_independent_on_device(ebo, orc, synth, config, n_events):
+@pytest.mark.parametrize("iters", [1, 4, 8, 12, 16, 20])
+def test_solve_independent_on_device(ebo, orc, synth, config, n_events, iters):
     """Per-patch LM entirely on the device vs the oracle's per-patch LM."""
     ev, _ = synth.make_window(config, n_events=n_events)
     with ctx_for(ebo, synth, config, tv_weight=0.0) as c:
         c.set_window(ev)
-        flows, summ = c.solve(mode=ebo.SOLVE_INDEPENDENT)
+        flows, summ = c.solve(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=iters)
         prm = oparams(orc, c.params)
-        fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(mode=1), want_image=False)
+        fo, _, so = orc.compensate_events_contrast(
+            ev, prm, orc.default_solver(mode=1, max_num_iterations=iters), want_image=False)
         _check_flows(flows[0], fo)
+        # same decisions: same number of cost-only and Jacobian evaluations
         assert summ[0].num_evals_jac == so.num_evals_jac
         assert summ[0].num_evals_cost == so.num_evals_cost
         assert summ[0].iterations == so.iterations
+
+
+def test_solve_independent_full_run_invariants(ebo, orc, synth):
+    """Full 50 iterations, TV-free: both sides are past the chaos horizon, so compare
+    what is well defined: the objective at the returned flows (recomputed by the
+    oracle) never exceeds the objective at the start, and the device's solution is as
+    good as the oracle's on aggregate."""
+    ev, _ = synth.make_window(2, n_events=50000)
+    with ctx_for(ebo, synth, 2, tv_weight=0.0) as c:
+        c.set_window(ev)
+        flows, summ = c.solve(mode=ebo.SOLVE_INDEPENDENT)
+        prm = oparams(orc, c.params)
+        fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(mode=1), want_image=False)
+        assert np.isfinite(flows).all()
+        r0, _, active, _ = orc.window_eval(ev, prm, np.zeros((c.P, 2)), want_jac=False)
+        rg, _, _, _ = orc.window_eval(ev, prm, flows[0], want_jac=False)
+        ro, _, _, _ = orc.window_eval(ev, prm, fo, want_jac=False)
+        a = active == 1
+        assert np.all(rg[a] <= r0[a] + 1e-9)  # LM returns the lowest-cost point visited
+        # aggregate quality within 2 % of the oracle's own (variance gain = 1000 - r)
+        gain_g, gain_o = (r0[a] - rg[a]).sum(), (r0[a] - ro[a]).sum()
+        assert gain_g >= 0.98 * gain_o
+        # most patches still coincide to 1e-5 even after 50 iterations
+        d = np.abs(flows[0] - fo).max(axis=1)
+        assert (d <= 1e-5).mean() >= 0.5
+        assert summ[0].iterations <= 50 and summ[0].termination in (0, 1)
 
 
 def test_solve_global_with_tv_matches_reference_problem(ebo, orc, synth):
@@ -277,15 +313,19 @@ def test_solve_global_with_tv_matches_reference_problem(ebo, orc, synth):
         assert summ[0].final_cost == pytest.approx(so.final_cost, rel=1e-9)
 
 
-def test_solve_global_without_tv(ebo, orc, synth):
+@pytest.mark.parametrize("iters", [6, 12, 18])
+def test_solve_global_without_tv(ebo, orc, synth, iters):
+    """One global trust region over all patches, no TV (host LM + device evaluations)."""
     ev, _ = synth.make_window(0, n_events=12000)
     with ctx_for(ebo, synth, 0, tv_weight=0.0) as c:
         c.set_window(ev)
-        flows, summ = c.solve(mode=ebo.SOLVE_GLOBAL)
+        flows, summ = c.solve(mode=ebo.SOLVE_GLOBAL, max_num_iterations=iters)
         fo, _, so = orc.compensate_events_contrast(
-            ev, oparams(orc, c.params), orc.default_solver(mode=0), want_image=False)
+            ev, oparams(orc, c.params), orc.default_solver(mode=0, max_num_iterations=iters),
+            want_image=False)
         _check_flows(flows[0], fo)
         assert summ[0].iterations == so.iterations
+        assert summ[0].num_evals_jac == so.num_evals_jac
 
 
 def test_compensate_events_contrast_one_call(ebo, orc, synth):

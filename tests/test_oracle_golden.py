@@ -281,3 +281,26 @@ def test_solver_tv_couples_patches(orc, synth):
     # ... and the two problems are different problems
     assert s.iterations <= 8
     assert f_tv.shape == (108, 2)
+
+
+def test_tv_free_solve_is_chaotic_on_the_cpu_alone(orc, synth):
+    """Evidence for how solver parity is tested on the GPU: without the TV terms the
+    reference's own formulation is chaotic.  Perturbing compensateScale by ONE ulp
+    leaves the CPU path's answer unchanged to ~1e-9 for the first ~20 LM iterations
+    and moves it by more than 1e-2 px/ms after 50.  With the reference's TV coupling
+    (its default) the same perturbation changes nothing measurable."""
+    ev, _ = synth.make_window(0, n_events=15000)
+
+    def solve(tv, scale, iters, mode):
+        prm = orc.default_params(loss=1, tv_weight=tv, scale=scale)
+        f, _, _ = orc.compensate_events_contrast(
+            ev, prm, orc.default_solver(mode=mode, max_num_iterations=iters), want_image=False)
+        return f
+
+    s0, s1 = 1e-3, float(np.nextafter(1e-3, 1.0))
+    d20 = np.abs(solve(0.0, s0, 20, 1) - solve(0.0, s1, 20, 1)).max()
+    d50 = np.abs(solve(0.0, s0, 50, 1) - solve(0.0, s1, 50, 1)).max()
+    assert d20 < 1e-7
+    assert d50 > 1e-2
+    tv50 = np.abs(solve(1e3, s0, 50, 0) - solve(1e3, s1, 50, 0)).max()
+    assert tv50 < 1e-9
