@@ -90,6 +90,7 @@ struct EvalLaunch
 	                       // 1: scatter value / gather derivatives, f64 atomics
 	                       // 2: same with exact fixed-point (u64) accumulation
 	int cap_doubles;       // impl 1/2: image capacity of one workgroup's LDS, in pixels
+	int rotate;            // impl 1/2: per-lane tap rotation in the scatter pass
 	size_t lds_bytes;
 	double* d_partials;    // [flow sets][n_units][tiles][kPartialStride]
 	double* d_out;         // [n_flow][3]

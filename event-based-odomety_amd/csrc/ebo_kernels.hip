@@ -345,9 +345,30 @@ __device__ __forceinline__ void block_minmax(int& xmin, int& xmax, int& ymin, in
 	}
 }
 
+// w'[k] = w[(k + r) mod 7], r in 0..6: a 3-stage barrel rotation on registers
+// (v_cndmask only; a runtime-indexed register array would go to scratch).
+__device__ __forceinline__ void rotate7(double (&w)[7], int r)
+{
+	if (r & 1)
+	{
+		const double t = w[0];
+		w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = w[5]; w[5] = w[6]; w[6] = t;
+	}
+	if (r & 2)
+	{
+		const double t0 = w[0], t1 = w[1];
+		w[0] = w[2]; w[1] = w[3]; w[2] = w[4]; w[3] = w[5]; w[4] = w[6]; w[5] = t0; w[6] = t1;
+	}
+	if (r & 4)
+	{
+		const double t0 = w[0], t1 = w[1], t2 = w[2], t3 = w[3];
+		w[0] = w[4]; w[1] = w[5]; w[2] = w[6]; w[3] = t0; w[4] = t1; w[5] = t2; w[6] = t3;
+	}
+}
+
 // The seven sums of one (unit, row band) at flow (m0, m1); every thread returns
 // the same totals.  lds: [red 128][int scratch 32][image capDoubles].
-template <bool FIXED>
+template <bool FIXED, bool ROT>
 __device__ __forceinline__ void eval_unit2(const uint64_t* __restrict__ ev, const Unit& u, double m0,
 											double m1, bool wantJac, int tile, int tiles,
 											int capDoubles, const EvalConsts& c, double* lds,
@@ -394,6 +415,9 @@ __device__ __forceinline__ void eval_unit2(const uint64_t* __restrict__ ev, cons
 	const int ty1 = min(ty0 + R, y1 + 1);
 	const int maxRows = max(capDoubles / cols, 1);
 	const unsigned long long biasBits = static_cast<unsigned long long>(__double_as_longlong(c.fix_bias));
+	const int lane = threadIdx.x & 63;
+	const int rotRow = ROT ? (lane % 7) : 0;
+	const int rotCol = ROT ? ((lane / 7) % 7) : 0;
 
 	for (int sy0 = ty0; sy0 < ty1; sy0 += maxRows)
 	{
@@ -424,33 +448,42 @@ __device__ __forceinline__ void eval_unit2(const uint64_t* __restrict__ ev, cons
 			axis_taps(fx, c.norm, c, wx);
 			axis_taps(fy, 1.0, c, wy);
 			const int colLo = pxc - 3 - x0;
+			// Tap rotation: lane l walks the 7x7 taps starting at (l%7, (l/7)%7).  Two
+			// lanes whose events share a centre pixel then never address the same pixel
+			// in the same wave instruction (same-address LDS atomics serialise).
+			rotate7(wy, rotRow);
+			rotate7(wx, rotCol);
 #pragma unroll
-			for (int j = 0; j < 7; ++j)
+			for (int jr = 0; jr < 7; ++jr)
 			{
+				int j = jr + rotRow;
+				j -= (j >= 7) ? 7 : 0;
 				const int row = rowLo + j;
 				if (row < 0 || row >= srows)
 				{
 					continue;
 				}
-				const int base = row * cols + colLo;
+				const int rowBase = row * cols + colLo;
 #pragma unroll
-				for (int i = 0; i < 7; ++i)
+				for (int ir = 0; ir < 7; ++ir)
 				{
+					int i = ir + rotCol;
+					i -= (i >= 7) ? 7 : 0;
 					const int col = colLo + i;
 					if (col < 0 || col >= cols)
 					{
 						continue;
 					}
-					const double v = wx[i] * wy[j];
+					const double v = wx[ir] * wy[jr];
 					if (FIXED)
 					{
 						const unsigned long long q =
 							static_cast<unsigned long long>(__double_as_longlong(v + c.fix_bias)) - biasBits;
-						atomicAdd(&imgq[base + i], q);
+						atomicAdd(&imgq[rowBase + i], q);
 					}
 					else
 					{
-						atomicAdd(&img[base + i], v);
+						atomicAdd(&img[rowBase + i], v);
 					}
 				}
 			}
@@ -551,7 +584,7 @@ __device__ __forceinline__ void eval_unit2(const uint64_t* __restrict__ ev, cons
 	block_sum<7>(S, red);
 }
 
-template <bool FIXED>
+template <bool FIXED, bool ROT>
 __global__ void __launch_bounds__(512) k_eval2(const uint64_t* __restrict__ events, const Unit* __restrict__ units,
 						const double* __restrict__ flows, int tiles, int wantJac, int capDoubles,
 						double fdStep, double* __restrict__ partials, double* __restrict__ out,
@@ -580,7 +613,8 @@ __global__ void __launch_bounds__(512) k_eval2(const uint64_t* __restrict__ even
 	double m1 = flows[2 * u.flow_idx + 1];
 	fd_offset(set, fdStep, m0, m1);
 	double S[7];
-	eval_unit2<FIXED>(events + u.ev_off, u, m0, m1, wantJac != 0, tile, tiles, capDoubles, c, lds, S);
+	eval_unit2<FIXED, ROT>(events + u.ev_off, u, m0, m1, wantJac != 0, tile, tiles, capDoubles, c, lds,
+						   S);
 	if (threadIdx.x == 0)
 	{
 		if (fused)
@@ -783,7 +817,7 @@ __device__ __forceinline__ void eval_unit(const uint64_t* __restrict__ ev, const
 										   double& j1)
 {
 	double S[7];
-	eval_unit2<FIXED>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+	eval_unit2<FIXED, true>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
 	j0 = 0.0;
 	j1 = 0.0;
 	variance_from_sums(S, wantJac, m0, m1, c.max_res, r, j0, j1);
@@ -1197,7 +1231,8 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 	}
 	else
 	{
-		auto kern = (L.impl == 2) ? k_eval2<true> : k_eval2<false>;
+		auto kern = (L.impl == 2) ? (L.rotate ? k_eval2<true, true> : k_eval2<true, false>)
+								  : (L.rotate ? k_eval2<false, true> : k_eval2<false, false>);
 		if (allow_big_lds(kern, L.lds_bytes))
 		{
 			return -2;
