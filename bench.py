@@ -216,6 +216,14 @@ def main():
 
     if rank == 0:
         base = cpu_baseline(synth, args.config, args.cpu_seconds) if world == 1 else None
+        # HBM traffic of the dominant kernel per launch, from the committed PMC profile of
+        # this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("workload") == cfg["name"] and t.get("windows") == Wn:
+                traffic = t.get("k_eval2_hbm_bytes_per_launch")
         value = total_events * args.steps / dt / 1e6
         line = {
             "metric": "Mevents/s warped+scored (value+Jacobian of the variance-contrast objective)",
@@ -228,10 +236,10 @@ def main():
                        "parallelism": "windows sharded over %d GPU(s)%s" % (
                            world, ", RCCL all-gather of (r,J) per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_eval_variance<3>", "kernel_ms": kern_ms,
-                         "note": "algorithmic 8 B/event-evaluation; the kernel is bound by f64 LDS "
-                                 "atomics + f64 VALU, not HBM (DESIGN.md)"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_eval2<true,true>", "kernel_ms": kern_ms,
+                         "note": "algorithmic 8 B/event-evaluation; the kernel is bound by LDS "
+                                 "atomics + f64 VALU, not HBM (DESIGN.md section 4)"},
             "cpu_baseline": base,
             "extras": extras,
         }

@@ -464,6 +464,15 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	L.n_windows = c->n_windows;
 	L.units_per_window = c->P + 1;
 	L.mode = mode;
+	{
+		const char* v = std::getenv("EBO_COUNT_IMPL");
+		L.impl = (v && *v) ? std::atoi(v) : -1;
+	}
+	L.max_window_events = 0;
+	for (const WindowInfo& wi : c->windows)
+	{
+		L.max_window_events = std::max<uint64_t>(L.max_window_events, wi.n_events);
+	}
 	L.d_aux = d_aux;
 	L.d_counts = c->d_counts;
 	L.d_image = d_image;
@@ -546,9 +555,16 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 		worst = std::max(worst, s.termination);
 		if (summary)
 		{
+			// counts are per data term (one contrastFunctor evaluation each), as the
+			// per-patch solver reports them
+			int nActive = 0;
+			for (int p = 0; p < P; ++p)
+			{
+				nActive += (c->units[static_cast<size_t>(w) * (P + 1) + p].flags & kUnitActive) ? 1 : 0;
+			}
 			summary[w].iterations = s.iterations;
-			summary[w].num_evals_cost = s.evals_cost;
-			summary[w].num_evals_jac = s.evals_jac;
+			summary[w].num_evals_cost = s.evals_cost * nActive;
+			summary[w].num_evals_jac = s.evals_jac * nActive;
 			summary[w].termination = s.termination;
 			summary[w].initial_cost = s.initial_cost;
 			summary[w].final_cost = s.final_cost;

@@ -1114,6 +1114,117 @@ __global__ void k_count_scatter(const uint64_t* __restrict__ events, const Unit*
 	}
 }
 
+// LDS-privatised count image: workgroup = (row band, window).  The band's counters
+// live in LDS (16-bit counters packed two per dword when the window has < 65536
+// events, else 32-bit); the workgroup streams ALL events of its window once
+// (8 B/lane coalesced; with more than one band the re-reads are L2 hits), counts
+// those that land in its band with ds_add_u32, and writes the finished f64 rows
+// with plain coalesced stores.  HBM traffic = events once + image once: no global
+// atomics, no int32 intermediate image.  Bit-exact (integer adds commute).
+template <bool U16>
+__global__ void __launch_bounds__(1024) k_count_window_lds(
+	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
+	int mode, const void* __restrict__ aux, int rowsPerBand, double* __restrict__ image,
+	EvalConsts c)
+{
+	extern __shared__ unsigned int cnt[];
+	const int w = blockIdx.y;
+	const int row0 = blockIdx.x * rowsPerBand;
+	const int rows = min(rowsPerBand, c.image_h - row0);
+	const int W = c.image_w;
+	const int npx = rows * W;
+	const int nWords = U16 ? (npx + 1) >> 1 : npx;
+	for (int i = threadIdx.x; i < nWords; i += blockDim.x)
+	{
+		cnt[i] = 0u;
+	}
+	__syncthreads();
+	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
+	const uint32_t evBegin = wu[0].ev_off;
+	const uint32_t evEnd = wu[unitsPerWindow - 1].ev_off + wu[unitsPerWindow - 1].n_ev;
+	const int P = c.npx * c.npy;
+	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
+	const double* flows = static_cast<const double*>(aux);
+	int ui = 0;
+	uint32_t uEnd = wu[0].ev_off + wu[0].n_ev;
+	double m0 = 0.0, m1 = 0.0;
+	int dtWin = wu[0].dt_win;
+	bool stray = (wu[0].flags & kUnitStray) != 0;
+	if (mode == 1 && !stray)
+	{
+		m0 = flows[2 * wu[0].flow_idx];
+		m1 = flows[2 * wu[0].flow_idx + 1];
+	}
+	for (uint32_t e = evBegin + threadIdx.x; e < evEnd; e += blockDim.x)
+	{
+		while (e >= uEnd)  // events are stored unit by unit: advance to the owning unit
+		{
+			++ui;
+			uEnd = wu[ui].ev_off + wu[ui].n_ev;
+			dtWin = wu[ui].dt_win;
+			stray = (wu[ui].flags & kUnitStray) != 0;
+			if (mode == 1 && !stray)
+			{
+				m0 = flows[2 * wu[ui].flow_idx];
+				m1 = flows[2 * wu[ui].flow_idx + 1];
+			}
+		}
+		int x, y, pos, dt;
+		unpack(events[e], x, y, pos, dt);
+		int nx = x, ny = y;
+		if (mode != 0)
+		{
+			if (mode == 1 && stray)
+			{
+				const int px = max(min(x / c.patch_w, c.npx - 1), 0);
+				const int py = max(min(y / c.patch_h, c.npy - 1), 0);
+				m0 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px)];
+				m1 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px) + 1];
+			}
+			if (mode == 2)
+			{
+				if (x < 0 || x >= W || y < 0 || y >= c.image_h)
+				{
+					continue;
+				}
+				const float* field = static_cast<const float*>(aux) +
+									 2 * (static_cast<size_t>(w) * imgSize + static_cast<size_t>(y) * W + x);
+				m0 = static_cast<double>(field[0]);
+				m1 = static_cast<double>(field[1]);
+			}
+			const double dtw = static_cast<double>(dt + dtWin);
+			const double fx = static_cast<double>(x) + dtw * c.scale * m0;
+			const double fy = static_cast<double>(y) + dtw * c.scale * m1;
+			if (!convertible(fx) || !convertible(fy))
+			{
+				continue;
+			}
+			nx = static_cast<int>(round(fx));
+			ny = static_cast<int>(round(fy));
+		}
+		const int ry = ny - row0;
+		if (nx >= 0 && nx < W && ry >= 0 && ry < rows)
+		{
+			const int p = ry * W + nx;
+			if (U16)
+			{
+				atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
+			}
+			else
+			{
+				atomicAdd(&cnt[p], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W;
+	for (int p = threadIdx.x; p < npx; p += blockDim.x)
+	{
+		const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
+		out[p] = static_cast<double>(v);
+	}
+}
+
 // int32 counts -> f64 image (the reference's CV_64F); re-zeroes the scratch.
 __global__ void k_counts_to_f64(int32_t* __restrict__ counts, double* __restrict__ image, size_t n)
 {
@@ -1288,6 +1399,28 @@ int launch_count_image(const CountLaunch& L, void* stream)
 {
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	const size_t n = static_cast<size_t>(L.n_windows) * L.c.image_w * L.c.image_h;
+	// LDS-privatised path when the image splits into few row bands and there are
+	// enough (band, window) workgroups to occupy the chip; else global int atomics.
+	{
+		const bool u16 = L.max_window_events < 65536;
+		const size_t ldsBytes = 128 * 1024;
+		const size_t pxPerBand = u16 ? ldsBytes / 2 : ldsBytes / 4;
+		const int rowsPerBand = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
+		const int bands = rowsPerBand > 0 ? (L.c.image_h + rowsPerBand - 1) / rowsPerBand : 1 << 30;
+		const bool want = L.impl == 1 || (L.impl < 0 && bands <= 4 && L.n_windows * bands >= 64);
+		if (want && rowsPerBand > 0 && L.n_units_total > 0)
+		{
+			auto kern = u16 ? k_count_window_lds<true> : k_count_window_lds<false>;
+			const size_t lds = (static_cast<size_t>(rowsPerBand) * L.c.image_w * (u16 ? 2 : 4) + 3) & ~size_t(3);
+			if (allow_big_lds(kern, lds))
+			{
+				return -2;
+			}
+			hipLaunchKernelGGL(kern, dim3(bands, L.n_windows), dim3(1024), lds, s, L.d_events, L.d_units,
+							   L.units_per_window, L.mode, L.d_aux, rowsPerBand, L.d_image, L.c);
+			return check_launch();
+		}
+	}
 	if (L.n_units_total > 0)
 	{
 		hipLaunchKernelGGL(k_count_scatter, dim3(L.n_units_total), dim3(256), 0, s, L.d_events,

@@ -1,0 +1,61 @@
+"""GPU tests of the two count-image implementations (global int atomics vs
+LDS-privatised row bands): both bit-exact against the oracle, on single windows
+and on batches, for all three modes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _prm(orc, c):
+    p = c.params
+    return orc.default_params(image_w=p.image_w, image_h=p.image_h, patch_w=p.patch_w,
+                              patch_h=p.patch_h, scale=p.scale, min_events=p.min_events, loss=1)
+
+
+@pytest.mark.parametrize("impl", ["0", "1", "auto"])
+@pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000)])
+def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config, n_windows, n_events):
+    if impl == "auto":
+        monkeypatch.delenv("EBO_COUNT_IMPL", raising=False)
+    else:
+        monkeypatch.setenv("EBO_COUNT_IMPL", impl)
+    cfg = synth.CONFIGS[config]
+    ev, offsets, gt = synth.make_stream(config, n_windows, n_events=n_events)
+    # a few events outside the sensor in the first window (stray bucket)
+    ev["x"][5] = -7
+    ev["y"][9] = cfg["image"][1] + 3
+    with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                     patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE, max_windows=n_windows,
+                     max_events=len(ev)) as c:
+        c.set_windows(ev, offsets)
+        prm = _prm(orc, c)
+        w, h = cfg["image"]
+        rng = np.random.RandomState(17)
+        flows = rng.uniform(-2, 2, (n_windows, c.P, 2))
+        field = rng.uniform(-2, 2, (n_windows, h, w, 2)).astype(np.float32)
+        integ = c.count_image(ebo.COUNT_INTEGRATED)
+        warped = c.count_image(ebo.COUNT_WARPED, flows)
+        byfield = c.count_image(ebo.COUNT_FIELD, field)
+        again = c.count_image(ebo.COUNT_INTEGRATED)
+        for k in sorted(set([0, n_windows // 2, n_windows - 1])):
+            sub = ev[int(offsets[k]):int(offsets[k + 1])]
+            assert np.array_equal(integ[k], orc.integrate_events(sub, w, h))
+            assert np.array_equal(warped[k], orc.final_count_image(sub, prm, flows[k]))
+            assert np.array_equal(byfield[k], orc.compensate_events_field(sub, w, h, field[k]))
+            assert np.array_equal(again[k], integ[k])
+
+
+def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypatch):
+    """16-bit packed counters are only used below 65536 events per window."""
+    monkeypatch.setenv("EBO_COUNT_IMPL", "1")
+    cfg = synth.CONFIGS[2]
+    ev, _ = synth.make_window(2, n_events=90000)
+    ev["x"][:70000] = 11  # 70000 events on ONE pixel: would overflow a 16-bit counter
+    ev["y"][:70000] = 13
+    with ebo.Context(image_w=240, image_h=180, patch_w=30, patch_h=22, loss=ebo.LOSS_VARIANCE,
+                     max_events=len(ev)) as c:
+        c.set_window(ev)
+        img = c.count_image(ebo.COUNT_INTEGRATED)[0]
+        assert img[13, 11] >= 70000
+        assert np.array_equal(img, orc.integrate_events(ev, 240, 180))
