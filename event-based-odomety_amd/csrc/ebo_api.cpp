@@ -468,6 +468,7 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 		const char* v = std::getenv("EBO_COUNT_IMPL");
 		L.impl = (v && *v) ? std::atoi(v) : -1;
 	}
+	L.lds_kb = static_cast<int>(std::min<size_t>(env_size("EBO_COUNT_LDS_KB", 0), 160));
 	L.max_window_events = 0;
 	for (const WindowInfo& wi : c->windows)
 	{

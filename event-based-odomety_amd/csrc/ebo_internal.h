@@ -125,6 +125,7 @@ struct CountLaunch
 	int units_per_window; // P + 1
 	int mode;             // EBO_COUNT_*
 	int impl;             // -1 auto, 0 global int atomics + convert, 1 LDS-privatised bands
+	int lds_kb;           // LDS per band workgroup (0 = 128 KiB)
 	uint64_t max_window_events;
 	const void* d_aux;    // flows f64 [Wn][P][2] or field f32 [Wn][H][W][2]
 	int32_t* d_counts;    // [Wn][H][W] scratch, zero on entry, zero on exit

@@ -1155,8 +1155,26 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 		m0 = flows[2 * wu[0].flow_idx];
 		m1 = flows[2 * wu[0].flow_idx + 1];
 	}
-	for (uint32_t e = evBegin + threadIdx.x; e < evEnd; e += blockDim.x)
+	// kInFlight independent 8-byte loads per lane are issued before the first is
+	// consumed: ~64 KiB in flight per CU, enough to cover HBM latency (Little's law).
+	constexpr int kInFlight = 8;
+	for (uint32_t eb = evBegin + threadIdx.x; eb < evEnd; eb += kInFlight * blockDim.x)
 	{
+		uint64_t recs[kInFlight];
+#pragma unroll
+		for (int k = 0; k < kInFlight; ++k)
+		{
+			const uint32_t ek = eb + k * blockDim.x;
+			recs[k] = (ek < evEnd) ? events[ek] : 0ull;
+		}
+#pragma unroll
+		for (int k = 0; k < kInFlight; ++k)
+		{
+		const uint32_t e = eb + k * blockDim.x;
+		if (e >= evEnd)
+		{
+			break;
+		}
 		while (e >= uEnd)  // events are stored unit by unit: advance to the owning unit
 		{
 			++ui;
@@ -1170,7 +1188,7 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 			}
 		}
 		int x, y, pos, dt;
-		unpack(events[e], x, y, pos, dt);
+		unpack(recs[k], x, y, pos, dt);
 		int nx = x, ny = y;
 		if (mode != 0)
 		{
@@ -1215,13 +1233,32 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 				atomicAdd(&cnt[p], 1u);
 			}
 		}
+		}  // k
 	}
 	__syncthreads();
 	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W;
-	for (int p = threadIdx.x; p < npx; p += blockDim.x)
+	if (U16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
 	{
-		const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
-		out[p] = static_cast<double>(v);
+		// one packed dword = two pixels = one 16-byte store
+		const int pairs = npx >> 1;
+		double2* out2 = reinterpret_cast<double2*>(out);
+		for (int i = threadIdx.x; i < pairs; i += blockDim.x)
+		{
+			const unsigned int v = cnt[i];
+			out2[i] = make_double2(static_cast<double>(v & 0xFFFFu), static_cast<double>(v >> 16));
+		}
+		if ((npx & 1) && threadIdx.x == 0)
+		{
+			out[npx - 1] = static_cast<double>(cnt[pairs] & 0xFFFFu);
+		}
+	}
+	else
+	{
+		for (int p = threadIdx.x; p < npx; p += blockDim.x)
+		{
+			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
+			out[p] = static_cast<double>(v);
+		}
 	}
 }
 
@@ -1403,7 +1440,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 	// enough (band, window) workgroups to occupy the chip; else global int atomics.
 	{
 		const bool u16 = L.max_window_events < 65536;
-		const size_t ldsBytes = 128 * 1024;
+		const size_t ldsBytes = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 128) * 1024;
 		const size_t pxPerBand = u16 ? ldsBytes / 2 : ldsBytes / 4;
 		const int rowsPerBand = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
 		const int bands = rowsPerBand > 0 ? (L.c.image_h + rowsPerBand - 1) / rowsPerBand : 1 << 30;
