@@ -240,6 +240,7 @@ class Context:
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self._check(lib().ebo_set_window(self._h, _vp(ev), C.c_size_t(len(ev))))
         self.n_windows = 1
+        self._custom = None
 
     def set_windows(self, ev, offsets):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
@@ -247,6 +248,21 @@ class Context:
         n = len(offsets) - 1
         self._check(lib().ebo_set_windows(self._h, _vp(ev), _vp(offsets), int(n)))
         self.n_windows = n
+        self._custom = None
+
+    def set_patches(self, ev, offsets, rects):
+        """Arbitrary patches (contrastFunctor instances): rects [n][4] = (x, y, w, h)."""
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        rects = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+        self._check(lib().ebo_set_patches(self._h, _vp(ev), _vp(offsets), _vp(rects), len(rects)))
+        self.n_windows = 1
+        self._custom = [tuple(int(v) for v in r) for r in rects]
+
+    @property
+    def cur_patches(self):
+        """Flows per window: grid patches, or the number given to set_patches."""
+        return len(self._custom) if getattr(self, "_custom", None) else self.P
 
     def window_info(self, w=0):
         t, n = C.c_int64(), C.c_uint64()
@@ -260,9 +276,10 @@ class Context:
 
     # -- objective -----------------------------------------------------------
     def eval(self, flows, want_jac=True):
-        flows = np.ascontiguousarray(flows, dtype=np.float64).reshape(self.n_windows, self.P, 2)
-        r = np.zeros((self.n_windows, self.P))
-        J = np.zeros((self.n_windows, self.P, 2)) if want_jac else None
+        P = self.cur_patches
+        flows = np.ascontiguousarray(flows, dtype=np.float64).reshape(self.n_windows, P, 2)
+        r = np.zeros((self.n_windows, P))
+        J = np.zeros((self.n_windows, P, 2)) if want_jac else None
         self._check(lib().ebo_eval(self._h, _dp(flows), _dp(r), _dp(J) if want_jac else None))
         return r, J
 
@@ -271,7 +288,10 @@ class Context:
             self._h, C.c_void_p(int(d_flows)), int(want_jac), C.c_void_p(int(d_out))))
 
     def contrast_image(self, patch, flow, channels=3, window=0):
-        x, y, w, h = self.patch_rect(patch % self.npx, patch // self.npx)
+        if getattr(self, "_custom", None):
+            x, y, w, h = self._custom[patch]
+        else:
+            x, y, w, h = self.patch_rect(patch % self.npx, patch // self.npx)
         flow = np.ascontiguousarray(flow, dtype=np.float64)
         img = np.zeros((channels, 3 * h, 3 * w))
         self._check(lib().ebo_contrast_image(
@@ -281,7 +301,7 @@ class Context:
     # -- solve ---------------------------------------------------------------
     def solve(self, opts=None, **kw):
         opts = opts if opts is not None else default_solver(**kw)
-        flows = np.zeros((self.n_windows, self.P, 2))
+        flows = np.zeros((self.n_windows, self.cur_patches, 2))
         summ = (Summary * self.n_windows)()
         self._check(lib().ebo_solve(self._h, C.byref(opts), _dp(flows), summ))
         return flows, list(summ)
@@ -320,6 +340,7 @@ class Context:
             self._h, _vp(ev), C.c_size_t(len(ev)), C.byref(opts), _dp(flows),
             _dp(img) if want_image else None, C.byref(s)))
         self.n_windows = 1
+        self._custom = None
         return flows, img, s
 
     # -- tracked-feature patches (Patch::integrate*) --------------------------

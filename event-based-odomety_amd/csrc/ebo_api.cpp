@@ -73,6 +73,18 @@ struct ebo_ctx
 
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int max_rw = 0, max_rh = 0;
+	int grid_max_rw = 0, grid_max_rh = 0;
+	int custom_n = 0;  // > 0: units were loaded by ebo_set_patches (arbitrary rects)
+
+	int cur_patches() const { return custom_n ? custom_n : P; }
+	size_t n_flows() const
+	{
+		return custom_n ? static_cast<size_t>(custom_n) : static_cast<size_t>(n_windows) * P;
+	}
+	size_t unit_index(int window, int patch) const
+	{
+		return custom_n ? static_cast<size_t>(patch) : static_cast<size_t>(window) * (P + 1) + patch;
+	}
 
 	int fail(int code, const std::string& msg)
 	{
@@ -273,7 +285,7 @@ int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
 	if (t <= 0)
 	{
 		t = fit;
-		const int nUnits = c->n_windows * c->P;
+		const int nUnits = static_cast<int>(c->n_flows());
 		// fill the chip (256 CUs) when there are few units, but keep >= 16 rows per tile
 		while (nUnits * t < 512 && (3 * c->max_rh) / (t + 1) >= 16)
 		{
@@ -308,7 +320,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
 	L.d_flows = d_flows;
-	L.n_flow = c->n_windows * c->P;
+	L.n_flow = static_cast<int>(c->n_flows());
 	L.flow_sets = central ? 5 : 1;
 	L.channels = (want_jac && !central) ? 3 : 1;
 	L.fd_step = central ? c->prm.fd_step : 0.0;
@@ -332,7 +344,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
 		if (t <= 0)
 		{
-			const int nUnits = std::max(1, c->n_windows * c->P);
+			const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
 			t = std::min(8, std::max(1, (1024 + nUnits - 1) / nUnits));
 		}
 		L.tiles = t;
@@ -358,7 +370,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 
 int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac)
 {
-	const size_t nf = static_cast<size_t>(c->n_windows) * c->P;
+	const size_t nf = c->n_flows();
 	int rc = c->hip(hipMemcpyAsync(c->d_flows, flows, nf * 2 * sizeof(double),
 								   hipMemcpyHostToDevice, c->stream),
 					"H2D flows");
@@ -457,6 +469,10 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 
 int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 {
+	if (c->custom_n)
+	{
+		return c->fail(EBO_ERR_STATE, "count images need a window (ebo_set_window), not ebo_set_patches");
+	}
 	CountLaunch L;
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
@@ -577,7 +593,7 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 
 int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary)
 {
-	const size_t nf = static_cast<size_t>(c->n_windows) * c->P;
+	const size_t nf = c->n_flows();
 	int rc = run_solve_device(c, o, c->d_flows, c->d_stats);
 	if (rc)
 	{
@@ -605,9 +621,10 @@ int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_o
 		{
 			ebo_summary s;
 			std::memset(&s, 0, sizeof(s));
-			for (int p = 0; p < c->P; ++p)
+			const int np = c->cur_patches();
+			for (int p = 0; p < np; ++p)
 			{
-				const int32_t* q = &st[(static_cast<size_t>(w) * c->P + p) * 4];
+				const int32_t* q = &st[(static_cast<size_t>(w) * np + p) * 4];
 				s.iterations = std::max(s.iterations, q[0]);
 				s.num_evals_cost += q[1];
 				s.num_evals_jac += q[2];
@@ -783,6 +800,8 @@ int ebo_create(const ebo_params* p, ebo_ctx** out)
 			c->max_rh = std::max(c->max_rh, h);
 		}
 	}
+	c->grid_max_rw = c->max_rw;
+	c->grid_max_rh = c->max_rh;
 	const size_t nf = static_cast<size_t>(c->cap_windows) * c->P;
 	const size_t npix = static_cast<size_t>(c->cap_windows) * p->image_w * p->image_h;
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -1036,6 +1055,117 @@ int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int 
 	c->unit_tref.swap(utref);
 	c->windows.swap(wins);
 	c->n_windows = n_windows;
+	c->custom_n = 0;
+	c->max_rw = c->grid_max_rw;
+	c->max_rh = c->grid_max_rh;
+	return EBO_OK;
+}
+
+int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, const int32_t* rects,
+					int n_patches)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!ev || !offsets || !rects || n_patches <= 0)
+	{
+		return c->fail(EBO_ERR_ARG, "null argument or no patch");
+	}
+	if (static_cast<size_t>(n_patches) > static_cast<size_t>(c->cap_windows) * c->P)
+	{
+		return c->fail(EBO_ERR_ARG, "more patches than max_windows * grid patches");
+	}
+	const size_t total = offsets[n_patches] - offsets[0];
+	if (total > c->cap_events)
+	{
+		return c->fail(EBO_ERR_ARG, "more events than max_events");
+	}
+	std::vector<Unit> units(n_patches);
+	std::vector<int64_t> utref(n_patches, 0);
+	c->h_packed.resize(total);
+	int mrw = 0, mrh = 0;
+	size_t base = 0;
+	for (int p = 0; p < n_patches; ++p)
+	{
+		if (offsets[p + 1] < offsets[p])
+		{
+			return c->fail(EBO_ERR_ARG, "offsets must be non-decreasing");
+		}
+		const ebo_event* pe = ev + offsets[p];
+		const size_t n = offsets[p + 1] - offsets[p];
+		const int32_t* r = rects + 4 * p;
+		if (r[2] <= 0 || r[3] <= 0 || r[2] > 10922 || r[3] > 10922 || r[0] < kCoordMin ||
+			r[0] > kCoordMax || r[1] < kCoordMin || r[1] > kCoordMax)
+		{
+			return c->fail(EBO_ERR_RANGE, "patch rect outside the packed range");
+		}
+		Unit& u = units[p];
+		u.ev_off = static_cast<uint32_t>(base);
+		u.n_ev = static_cast<uint32_t>(n);
+		u.rx = static_cast<int16_t>(r[0]);
+		u.ry = static_cast<int16_t>(r[1]);
+		u.rw = static_cast<int16_t>(r[2]);
+		u.rh = static_cast<int16_t>(r[3]);
+		u.dt_win = 0;
+		u.flags = (n > c->prm.min_events) ? kUnitActive : 0u;
+		u.flow_idx = static_cast<uint32_t>(p);
+		mrw = std::max(mrw, r[2]);
+		mrh = std::max(mrh, r[3]);
+		int64_t tu = 0;
+		if (n > 0 && !mid_timestamp(pe[0].t_us, pe[n - 1].t_us, tu))  // contrast_functor.h:18-20
+		{
+			return c->fail(EBO_ERR_RANGE, "patch mid-time outside int32 microseconds");
+		}
+		utref[p] = tu;
+		for (size_t i = 0; i < n; ++i)
+		{
+			if (pe[i].x < kCoordMin || pe[i].x > kCoordMax || pe[i].y < kCoordMin || pe[i].y > kCoordMax)
+			{
+				return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
+			}
+			const int64_t dt = tu - pe[i].t_us;
+			if (dt < INT32_MIN || dt > INT32_MAX)
+			{
+				return c->fail(EBO_ERR_RANGE, "event time further than 2^31 us from the reference time");
+			}
+			c->h_packed[base + i] =
+				static_cast<uint64_t>(pack_lo(pe[i].x, pe[i].y, pe[i].sign > 0)) |
+				(static_cast<uint64_t>(static_cast<uint32_t>(static_cast<int32_t>(dt))) << 32);
+		}
+		base += n;
+	}
+	(void)hipSetDevice(c->prm.device);
+	int rc = EBO_OK;
+	if (total > 0)
+	{
+		rc = c->hip(hipMemcpyAsync(c->d_events, c->h_packed.data(), total * sizeof(uint64_t),
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D events");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(Unit),
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D units");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipStreamSynchronize(c->stream), "sync after upload");
+	}
+	if (rc != EBO_OK)
+	{
+		c->n_windows = 0;
+		c->custom_n = 0;
+		return rc;
+	}
+	c->units.swap(units);
+	c->unit_tref.swap(utref);
+	c->windows.assign(1, WindowInfo{0, total});
+	c->n_windows = 1;
+	c->custom_n = n_patches;
+	c->max_rw = mrw;
+	c->max_rh = mrh;
 	return EBO_OK;
 }
 
@@ -1069,11 +1199,11 @@ int ebo_window_info(const ebo_ctx* c, int window, int64_t* t_ref_us, uint64_t* n
 int ebo_patch_info(const ebo_ctx* c, int window, int patch, int32_t* n_events, int32_t* active,
 				   int64_t* t_ref_us)
 {
-	if (!c || window < 0 || window >= c->n_windows || patch < 0 || patch >= c->P)
+	if (!c || window < 0 || window >= c->n_windows || patch < 0 || patch >= c->cur_patches())
 	{
 		return EBO_ERR_ARG;
 	}
-	const size_t i = static_cast<size_t>(window) * (c->P + 1) + patch;
+	const size_t i = c->unit_index(window, patch);
 	if (n_events) *n_events = static_cast<int32_t>(c->units[i].n_ev);
 	if (active) *active = (c->units[i].flags & kUnitActive) ? 1 : 0;
 	if (t_ref_us) *t_ref_us = c->unit_tref[i];
@@ -1119,12 +1249,12 @@ int ebo_contrast_image(ebo_ctx* c, int window, int patch, const double* flow, in
 		return EBO_ERR_ARG;
 	}
 	if (!flow || !image || (channels != 1 && channels != 3) || window < 0 ||
-		window >= c->n_windows || patch < 0 || patch >= c->P)
+		window >= c->n_windows || patch < 0 || patch >= c->cur_patches())
 	{
 		return c->fail(EBO_ERR_ARG, "bad argument to ebo_contrast_image");
 	}
 	(void)hipSetDevice(c->prm.device);
-	const size_t ui = static_cast<size_t>(window) * (c->P + 1) + patch;
+	const size_t ui = c->unit_index(window, patch);
 	const Unit& u = c->units[ui];
 	const size_t npx = static_cast<size_t>(9) * u.rw * u.rh;
 	int rc = ensure_aux(c, npx * channels * sizeof(double) + 2 * sizeof(double));
@@ -1188,6 +1318,10 @@ int ebo_solve(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summa
 	if (o->mode == EBO_SOLVE_INDEPENDENT)
 	{
 		return solve_independent_host(c, o, flows_out, summary);
+	}
+	if (c->custom_n)
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED, "EBO_SOLVE_GLOBAL needs the patch grid of a window");
 	}
 	return solve_global(c, o, flows_out, summary);
 }

@@ -158,6 +158,14 @@ int ebo_patch_rect(const ebo_ctx* ctx, int px, int py, int* x, int* y, int* w, i
 int ebo_set_window(ebo_ctx* ctx, const ebo_event* ev, size_t n);
 /* Batch of independent windows: window w = ev[offsets[w] .. offsets[w+1]). */
 int ebo_set_windows(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets, int n_windows);
+/* Arbitrary patches instead of a window: patch i = cv::Rect2i rects[i][4] = (x,y,w,h)
+ * with its own event list ev[offsets[i]..offsets[i+1]) in list order, exactly what
+ * tracker::contrastFunctor's constructor takes (contrast_functor.h:12-21; events
+ * are NOT filtered by the rect, as there).  Afterwards ebo_eval / ebo_solve
+ * (EBO_SOLVE_INDEPENDENT) / ebo_contrast_image address n_patches flows [n][2] with
+ * window = 0.  n_patches <= max_windows * grid patches. */
+int ebo_set_patches(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets, const int32_t* rects,
+					int n_patches);
 int ebo_num_windows(const ebo_ctx* ctx, int* n_windows);
 int ebo_window_info(const ebo_ctx* ctx, int window, int64_t* t_ref_us, uint64_t* n_events);
 /* n_events in the patch, active = (n_events > min_events), functor reference time. */

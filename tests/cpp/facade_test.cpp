@@ -1,0 +1,232 @@
+// facade_test.cpp — the C++ façade (tracker::FeatureDetector, tracker::contrastFunctor,
+// tracker::ContrastBatch, tracker::totalVarianceFunctor) driven the way the reference's
+// evaluator drives it (tools/evaluator/src/evaluator.cpp:32-45), checked against the
+// CPU oracle.  Mirrors the style of the reference's own gtest files; gtest is not in
+// this image, so plain checks.  Run by tests/test_gpu_facade.py on the GPU box.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../event-based-odomety_amd/include/feature_tracker/contrast_functor.h"
+#include "../../event-based-odomety_amd/include/feature_tracker/feature_detector.h"
+#include "../../event-based-odomety_amd/include/feature_tracker/total_variance.h"
+#include "../../oracle/ebo_oracle.h"
+
+static int g_fail = 0;
+#define EXPECT_TRUE(c)                                                      \
+	do                                                                      \
+	{                                                                       \
+		if (!(c))                                                           \
+		{                                                                   \
+			std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c);        \
+			++g_fail;                                                       \
+		}                                                                   \
+	} while (0)
+#define EXPECT_NEAR(a, b, tol) EXPECT_TRUE(std::fabs((a) - (b)) <= (tol))
+
+static unsigned long long g_state = 88172645463325252ull;
+static unsigned rnd()
+{
+	g_state ^= g_state << 13;
+	g_state ^= g_state >> 7;
+	g_state ^= g_state << 17;
+	return static_cast<unsigned>(g_state >> 11);
+}
+
+// an edge drifting at (0.4, -0.2) px/ms plus noise, 240x180 sensor
+static std::vector<common::EventSample> makeEvents(int n)
+{
+	std::vector<common::EventSample> ev;
+	for (int i = 0; i < n; ++i)
+	{
+		const long t = 100000 + static_cast<long>(i) * 30000 / n;
+		const double dt = (t - 115000) * 1e-3;
+		common::EventSample e;
+		if (rnd() % 10 == 0)
+		{
+			e.value.point = {static_cast<int>(rnd() % 240), static_cast<int>(rnd() % 180)};
+		}
+		else
+		{
+			const double s = (rnd() % 2000) / 1000.0 - 1.0;
+			const int k = rnd() % 6;
+			const double cx = 30 + 36 * k, cy = 40 + 20 * k;
+			int x = static_cast<int>(cx + s * 9 + 0.4 * dt + (rnd() % 3) - 1);
+			int y = static_cast<int>(cy + s * 15 - 0.2 * dt + (rnd() % 3) - 1);
+			x = x < 0 ? 0 : (x > 239 ? 239 : x);
+			y = y < 0 ? 0 : (y > 179 ? 179 : y);
+			e.value.point = {x, y};
+		}
+		e.value.sign = (rnd() & 1) ? common::POSITIVE : common::NEGATIVE;
+		e.timestamp = common::timestamp_t(t);
+		ev.push_back(e);
+	}
+	return ev;
+}
+
+static std::vector<orc_event> toOracle(const std::list<common::EventSample>& l)
+{
+	std::vector<orc_event> out;
+	for (const auto& e : l)
+	{
+		out.push_back({e.value.point.x, e.value.point.y, static_cast<int32_t>(e.value.sign), 0, e.timestamp.count()});
+	}
+	return out;
+}
+
+int main()
+{
+	const auto samples = makeEvents(20000);
+
+	// ---- FeatureDetector in the evaluator's call order --------------------------------
+	tracker::DetectorParams params;  // reference defaults: 240x180, 20x20 patches, TV 1e3
+	params.loss = EBO_LOSS_VARIANCE;
+	tracker::FeatureDetector detector(params);
+	for (const auto& s : samples)
+	{
+		detector.addEvent(s);
+	}
+	EXPECT_TRUE(detector.getEvents().size() == 15000);  // capped at maxNumEventsToStore
+	EXPECT_TRUE(detector.getEvents().front().timestamp == samples[5000].timestamp);
+	const std::list<common::EventSample> window = detector.getEvents();
+	detector.compensateEventsContrast(detector.getEvents());
+	detector.integrateEvents(detector.getEvents());
+	EXPECT_TRUE(detector.getLastCompensation() == window.back().timestamp);
+	detector.clearEvents();
+	EXPECT_TRUE(detector.getEvents().empty());
+
+	const std::vector<orc_event> oev = toOracle(window);
+	orc_params op;
+	orc_default_params(&op);
+	op.loss = 1;
+	orc_solver_opts oo;
+	orc_default_solver(&oo);
+	const int P = detector.numPatchesX() * detector.numPatchesY();
+	EXPECT_TRUE(detector.numPatchesX() == 12 && detector.numPatchesY() == 9);
+	std::vector<double> oflows(2 * P), oimg(240 * 180), oint(240 * 180), oimg2(240 * 180);
+	orc_summary os;
+	orc_compensate_events_contrast(oev.data(), oev.size(), &op, &oo, oflows.data(), oimg.data(), &os);
+	double maxd = 0;
+	for (int i = 0; i < 2 * P; ++i)
+	{
+		maxd = std::fmax(maxd, std::fabs(oflows[i] - detector.getPatchFlows()[i]));
+	}
+	std::printf("FeatureDetector::compensateEventsContrast: max |flow - oracle| = %.3e, iterations %d vs %d\n",
+				maxd, detector.getLastSummary().iterations, os.iterations);
+	EXPECT_TRUE(maxd <= 1e-5);
+	EXPECT_TRUE(detector.getLastSummary().iterations == os.iterations);
+	// final image: bit exact for the same flows
+	orc_final_count_image(oev.data(), oev.size(), &op, detector.getPatchFlows().data(), oimg2.data());
+	orc_integrate_events(oev.data(), oev.size(), 240, 180, oint.data());
+	bool sameC = true, sameI = true;
+	double sum = 0;
+	for (int y = 0; y < 180; ++y)
+	{
+		for (int x = 0; x < 240; ++x)
+		{
+			sameC = sameC && detector.getCompensatedEventImage().at<double>(y, x) == oimg2[y * 240 + x];
+			sameI = sameI && detector.getIntegratedEventImage().at<double>(y, x) == oint[y * 240 + x];
+			sum += detector.getIntegratedEventImage().at<double>(y, x);
+		}
+	}
+	EXPECT_TRUE(sameC);
+	EXPECT_TRUE(sameI);
+	EXPECT_TRUE(sum == 15000.0);
+
+	// motion-field variant (compensateEvents): zero field == un-warped counts
+	detector.compensateEvents(window);
+	bool sameF = true;
+	for (int i = 0; i < 240 * 180; ++i)
+	{
+		sameF = sameF && detector.getCompensatedEventImage().ptr()[i] == oint[i];
+	}
+	EXPECT_TRUE(sameF);
+
+	// ---- contrastFunctor with the reference's constructor ---------------------------------
+	const tracker::Rect2i rect(20, 40, 20, 20);
+	std::list<common::EventSample> patchEvents;
+	for (const auto& e : window)
+	{
+		if (rect.contains(e.value.point))  // feature_detector.cpp:348-355
+		{
+			patchEvents.push_back(e);
+		}
+	}
+	EXPECT_TRUE(patchEvents.size() > 100);
+	tracker::contrastFunctor functor(patchEvents, rect, params.compensateScale, EBO_LOSS_VARIANCE);
+	const std::vector<orc_event> pev = toOracle(patchEvents);
+	orc_functor_consts k;
+	orc_default_consts(&k);
+	const double motions[3][2] = {{0.0, 0.0}, {0.4, -0.2}, {-0.7, 0.3}};
+	for (const auto& m : motions)
+	{
+		double r = 0, rj = 0, J[2] = {0, 0}, ro = 0, Jo[2];
+		EXPECT_TRUE(functor(m, &r));
+		const double* blocks[1] = {m};
+		double* jac[1] = {J};
+		EXPECT_TRUE(functor.Evaluate(blocks, &rj, jac));
+		orc_contrast_eval(pev.data(), pev.size(), rect.x, rect.y, rect.width, rect.height, 1e-3, &k, 1, m, &ro, Jo);
+		EXPECT_NEAR(r, ro, 1e-9 * std::fabs(ro));
+		EXPECT_NEAR(rj, ro, 1e-9 * std::fabs(ro));
+		EXPECT_NEAR(J[0], Jo[0], 1e-9 * std::fabs(Jo[0]) + 1e-10);
+		EXPECT_NEAR(J[1], Jo[1], 1e-9 * std::fabs(Jo[1]) + 1e-10);
+		double rv = 0;
+		EXPECT_TRUE(functor.Evaluate(blocks, &rv, nullptr));  // jacobians == nullptr: value only
+		EXPECT_NEAR(rv, ro, 1e-9 * std::fabs(ro));
+	}
+
+	// ---- ContrastBatch: every data term in one launch (the EvaluationCallback surface) ------
+	tracker::ContrastBatch batch(params.compensateScale, EBO_LOSS_VARIANCE);
+	std::vector<double> x(2 * 6, 0.0);
+	std::vector<std::list<common::EventSample>> lists(6);
+	std::vector<tracker::Rect2i> rects;
+	for (int i = 0; i < 6; ++i)
+	{
+		rects.emplace_back(20 + 36 * i, 30 + 20 * i, 24, 22);
+		for (const auto& e : window)
+		{
+			if (rects[i].contains(e.value.point))
+			{
+				lists[i].push_back(e);
+			}
+		}
+		x[2 * i] = 0.1 * i - 0.2;
+		x[2 * i + 1] = 0.05 * i;
+		batch.addPatch(lists[i], rects[i], &x[2 * i]);
+	}
+	batch.PrepareForEvaluation(true, true);
+	EXPECT_TRUE(batch.ok());
+	for (int i = 0; i < 6; ++i)
+	{
+		if (lists[i].empty())
+		{
+			continue;
+		}
+		const std::vector<orc_event> bev = toOracle(lists[i]);
+		double ro, Jo[2];
+		orc_contrast_eval(bev.data(), bev.size(), rects[i].x, rects[i].y, rects[i].width, rects[i].height, 1e-3, &k, 1,
+						  &x[2 * i], &ro, Jo);
+		EXPECT_NEAR(batch.residual(i), ro, 1e-9 * std::fabs(ro));
+		EXPECT_NEAR(batch.jacobian(i)[0], Jo[0], 1e-9 * std::fabs(Jo[0]) + 1e-10);
+		EXPECT_NEAR(batch.jacobian(i)[1], Jo[1], 1e-9 * std::fabs(Jo[1]) + 1e-10);
+	}
+
+	// ---- totalVarianceFunctor (host) ------------------------------------------------------------
+	tracker::totalVarianceFunctor tv(1e3);
+	const double a[2] = {0.5, -0.25}, b[2] = {0.25, 0.0};
+	double res[2], ores[2];
+	tv(a, b, res);
+	orc_tv_eval(1e3, a, b, ores, nullptr, nullptr);
+	EXPECT_TRUE(res[0] == ores[0] && res[1] == ores[1]);
+
+	// ---- error behaviour: no exceptions cross the functor, status instead ---------------------
+	std::list<common::EventSample> far = patchEvents;
+	far.back().timestamp += common::timestamp_t(1ll << 33);
+	tracker::contrastFunctor bad(far, rect, params.compensateScale, EBO_LOSS_VARIANCE);
+	double rr = 0;
+	EXPECT_TRUE(!bad(motions[0], &rr));
+
+	std::printf(g_fail ? "facade_test: %d FAILED\n" : "facade_test: all passed\n", g_fail);
+	return g_fail ? 1 : 0;
+}
