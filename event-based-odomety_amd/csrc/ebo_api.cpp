@@ -64,6 +64,8 @@ struct ebo_ctx
 	int32_t* d_stats = nullptr;
 	void* d_scratch = nullptr;  // patch-integrate staging
 	size_t scratch_cap = 0;
+	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
+	size_t edge_scratch_cap = 0;
 
 	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window
 	std::vector<int64_t> unit_tref;
@@ -303,16 +305,96 @@ int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
 	return EBO_OK;
 }
 
+// Edge loss (contrast_functor.h:152-277): one workgroup per unit, arrays in LDS, a
+// per-unit global slice as fallback for boxes that do not fit.
+int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out)
+{
+	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
+	EdgeLaunch L;
+	L.d_events = c->d_events;
+	L.d_units = c->d_units;
+	L.n_units = static_cast<int>(c->units.size());
+	L.d_flows = d_flows;
+	L.want_jac = (want_jac && !central) ? 1 : 0;
+	L.flow_sets = central ? 5 : 1;
+	L.fd_step = central ? c->prm.fd_step : 0.0;
+	L.block = static_cast<int>(env_size("EBO_EDGE_BLOCK", 256));
+	if (L.block < 64 || L.block > 512 || (L.block & 63))
+	{
+		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,512]");
+	}
+	const size_t headerBytes = 168 * sizeof(double);
+	const size_t canvasPx = static_cast<size_t>(9) * c->max_rw * c->max_rh;
+	const size_t bytesPerPx = 3 * sizeof(double) + sizeof(int32_t);
+	size_t ldsBytes = std::min<size_t>(env_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
+	// no point in reserving more LDS than the whole canvas needs
+	ldsBytes = std::min(ldsBytes, headerBytes + canvasPx * bytesPerPx + 64);
+	L.cap_px = static_cast<int>((ldsBytes - headerBytes) / bytesPerPx);
+	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * bytesPerPx;
+	L.scratch_stride = (canvasPx * bytesPerPx + 255) & ~static_cast<size_t>(255);
+	L.d_scratch = nullptr;
+	if (static_cast<size_t>(L.cap_px) < canvasPx)
+	{
+		// some box could exceed LDS: keep a global slice per (set, unit)
+		const size_t need = L.scratch_stride * L.n_units * L.flow_sets;
+		if (need > (static_cast<size_t>(16) << 30))
+		{
+			return c->fail(EBO_ERR_UNSUPPORTED, "edge loss fallback scratch would exceed 16 GiB; use fewer windows per batch");
+		}
+		if (need > c->edge_scratch_cap)
+		{
+			if (c->d_edge_scratch)
+			{
+				hipFree(c->d_edge_scratch);
+				c->d_edge_scratch = nullptr;
+				c->edge_scratch_cap = 0;
+			}
+			int rc = c->hip(hipMalloc(&c->d_edge_scratch, need), "hipMalloc edge scratch");
+			if (rc)
+			{
+				return rc;
+			}
+			c->edge_scratch_cap = need;
+		}
+		L.d_scratch = static_cast<char*>(c->d_edge_scratch);
+	}
+	int rc = ensure_partials(c, static_cast<size_t>(5) * L.n_units * 3);
+	if (rc)
+	{
+		return rc;
+	}
+	L.d_sets = c->d_partials;
+	L.d_out = d_out;
+	L.c = make_consts(c);
+	// weights exactly as the reference builds them (:193-202): gaussian(0, 0, j, i, sigmaST)
+	const double sig = c->prm.k.sigma_st;
+	const double sigmaSq = sig * sig;
+	const double normCoef = 1.0 / ((2 * M_PI) * sigmaSq);
+	for (int i = -3; i <= 3; ++i)
+	{
+		for (int j = -3; j <= 3; ++j)
+		{
+			const double x = j, y = i;
+			L.ec.w[(i + 3) * 7 + (j + 3)] = normCoef * std::exp(-0.5 / sigmaSq * (x * x + y * y));
+		}
+	}
+	L.ec.mean_threshold = 0.0001;
+	if (launch_eval_edge(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "edge eval launch");
+	}
+	return EBO_OK;
+}
+
 int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out)
 {
 	if (c->n_windows == 0)
 	{
 		return c->fail(EBO_ERR_STATE, "no window loaded");
 	}
-	if (c->prm.loss != EBO_LOSS_VARIANCE)
+	if (c->prm.loss == EBO_LOSS_EDGE)
 	{
-		return c->fail(EBO_ERR_UNSUPPORTED,
-					   "edge loss is not built on the device yet; use EBO_LOSS_VARIANCE");
+		return run_eval_edge(c, d_flows, want_jac, d_out);
 	}
 	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
 	EvalLaunch L;
@@ -591,8 +673,84 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 	return EBO_OK;
 }
 
+// EBO_SOLVE_INDEPENDENT when the device-resident solver does not cover the loss (edge
+// loss): one 2-parameter LM per active patch on the host, all of them advanced in lock
+// step so that each round is ONE batched device evaluation.
+int solve_independent_lockstep(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out,
+							   ebo_summary* summary)
+{
+	const size_t nf = c->n_flows();
+	const int np = c->cur_patches();
+	std::vector<HostLm> lms;
+	std::vector<size_t> slot;  // flow index of each LM
+	const std::vector<uint8_t> one(1, 1);
+	for (int w = 0; w < c->n_windows; ++w)
+	{
+		for (int p = 0; p < np; ++p)
+		{
+			if (c->units[c->unit_index(w, p)].flags & kUnitActive)
+			{
+				lms.emplace_back(1, 1, one, 0.0, c->prm.tv_huber, *o);
+				slot.push_back(static_cast<size_t>(w) * np + p);
+			}
+		}
+	}
+	std::vector<double> flows(nf * 2, 0.0), r(nf), J(nf * 2);
+	for (;;)
+	{
+		bool any = false, anyJac = false;
+		for (size_t k = 0; k < lms.size(); ++k)
+		{
+			const HostLm::Request q = lms[k].request(&flows[2 * slot[k]]);
+			if (q != HostLm::DONE)
+			{
+				any = true;
+				anyJac = anyJac || (q == HostLm::NEED_JACOBIAN);
+			}
+		}
+		if (!any)
+		{
+			break;
+		}
+		const int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr);
+		if (rc)
+		{
+			return rc;
+		}
+		for (size_t k = 0; k < lms.size(); ++k)
+		{
+			lms[k].supply(&r[slot[k]], anyJac ? &J[2 * slot[k]] : nullptr);
+		}
+	}
+	std::fill(flows_out, flows_out + nf * 2, 0.0);
+	if (summary)
+	{
+		std::memset(summary, 0, sizeof(ebo_summary) * c->n_windows);
+	}
+	for (size_t k = 0; k < lms.size(); ++k)
+	{
+		lms[k].result(flows_out + 2 * slot[k]);
+		if (summary)
+		{
+			const HostLm::Stats& s = lms[k].stats();
+			ebo_summary& d = summary[slot[k] / np];
+			d.iterations = std::max(d.iterations, s.iterations);
+			d.num_evals_cost += s.evals_cost;
+			d.num_evals_jac += s.evals_jac;
+			d.termination = std::max(d.termination, s.termination);
+			d.initial_cost += s.initial_cost;
+			d.final_cost += s.final_cost;
+		}
+	}
+	return EBO_OK;
+}
+
 int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary)
 {
+	if (c->prm.loss != EBO_LOSS_VARIANCE || c->prm.grad != EBO_GRAD_JET)
+	{
+		return solve_independent_lockstep(c, o, flows_out, summary);
+	}
 	const size_t nf = c->n_flows();
 	int rc = run_solve_device(c, o, c->d_flows, c->d_stats);
 	if (rc)
@@ -847,6 +1005,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_aux);
 	hipFree(c->d_stats);
 	hipFree(c->d_scratch);
+	hipFree(c->d_edge_scratch);
 	if (c->ev0) hipEventDestroy(c->ev0);
 	if (c->ev1) hipEventDestroy(c->ev1);
 	if (c->own_stream && c->stream)

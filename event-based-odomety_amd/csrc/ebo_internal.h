@@ -100,6 +100,34 @@ struct EvalLaunch
 int launch_eval_variance(const EvalLaunch& L, void* stream);
 int launch_dump_image(const EvalLaunch& L, int unit, double* d_image, void* stream);
 
+// Edge (structure-tensor) loss, contrast_functor.h:152-277.
+struct EdgeConsts
+{
+	double w[49];          // tensor weights [i+3][j+3] = gaussian(0,0,j,i,sigmaST) (:193-202)
+	double mean_threshold; // 1e-4 (:159)
+};
+
+struct EdgeLaunch
+{
+	const uint64_t* d_events;
+	const Unit* d_units;
+	int n_units;
+	const double* d_flows;
+	int want_jac;
+	int flow_sets;        // 1, or 5 (central differences, value only)
+	double fd_step;
+	int block;
+	int cap_px;           // pixels per array that fit LDS
+	size_t lds_bytes;
+	char* d_scratch;      // global fallback, [flow sets][n_units][stride]
+	size_t scratch_stride;
+	double* d_sets;       // staging [5][n_units][3] for central differences
+	double* d_out;        // [n_flow][3]
+	EvalConsts c;
+	EdgeConsts ec;
+};
+int launch_eval_edge(const EdgeLaunch& L, void* stream);
+
 struct SolveLaunch
 {
 	const uint64_t* d_events;

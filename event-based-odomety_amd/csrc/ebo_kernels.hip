@@ -1338,6 +1338,8 @@ __global__ void k_patch_integrate(const uint64_t* __restrict__ events,
 	}
 }
 
+#include "ebo_edge.inc"
+
 int check_launch()
 {
 	return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1398,6 +1400,32 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		hipLaunchKernelGGL(k_combine_variance, dim3((L.n_units + 127) / 128), dim3(128), 0, s,
 						   L.d_units, L.n_units, L.d_flows, L.tiles, L.flow_sets, L.channels,
 						   L.fd_step, L.d_partials, L.d_out, L.c);
+	}
+	return check_launch();
+}
+
+int launch_eval_edge(const EdgeLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (L.n_units == 0)
+	{
+		return 0;
+	}
+	if (allow_big_lds(k_eval_edge, L.lds_bytes))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_eval_edge, dim3(L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
+					   L.d_events, L.d_units, L.d_flows, L.want_jac, L.cap_px, L.fd_step, L.d_scratch,
+					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec);
+	if (check_launch())
+	{
+		return -2;
+	}
+	if (L.flow_sets == 5)
+	{
+		hipLaunchKernelGGL(k_edge_central, dim3((L.n_units + 127) / 128), dim3(128), 0, s, L.d_units,
+						   L.n_units, L.fd_step, L.d_sets, L.d_out);
 	}
 	return check_launch();
 }

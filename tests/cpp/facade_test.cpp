@@ -134,7 +134,12 @@ int main()
 	EXPECT_TRUE(sameI);
 	EXPECT_TRUE(sum == 15000.0);
 
+	// compensateEventsContrast left the solved flows at the patch corners of the motion
+	// field (feature_detector.cpp:418-431)
+	EXPECT_TRUE(detector.getMotionField()[2 * (20 * 240 + 20)] ==
+				static_cast<float>(detector.getPatchFlows()[2 * (1 * 12 + 1)]));
 	// motion-field variant (compensateEvents): zero field == un-warped counts
+	detector.setMotionField(std::vector<float>(240 * 180 * 2, 0.0f));
 	detector.compensateEvents(window);
 	bool sameF = true;
 	for (int i = 0; i < 240 * 180; ++i)

@@ -1,0 +1,147 @@
+"""GPU parity tests of the edge (structure-tensor) loss — the loss the reference's
+contrastFunctor::operator() actually calls (contrast_functor.h:33-34, :152-277):
+value, Jacobian (what Jet<double,2> propagates), penalty branch, fallback storage,
+central differences, and the solves on the reference's own configuration."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import GOLDEN, make_probe_input
+
+pytestmark = pytest.mark.gpu
+
+
+def oparams(orc, p):
+    return orc.default_params(
+        image_w=p.image_w, image_h=p.image_h, patch_w=p.patch_w, patch_h=p.patch_h,
+        tv_weight=p.tv_weight, tv_huber=p.tv_huber, scale=p.scale, min_events=p.min_events,
+        loss=p.loss)
+
+
+def ctx_for(ebo, synth, config, **kw):
+    cfg = synth.CONFIGS[config]
+    args = dict(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                patch_h=cfg["patch"][1], loss=ebo.LOSS_EDGE)
+    args.update(kw)
+    return ebo.Context(**args)
+
+
+def check_rj(r, J, ro, Jo):
+    np.testing.assert_allclose(r, ro, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(J, Jo, rtol=1e-8, atol=1e-12)
+
+
+def test_probe_digits_edge_loss_through_the_hip_path(ebo, orc):
+    """SURVEY §8(c) digits of the reference's edge loss, evaluated by the HIP kernels."""
+    gold = json.load(open(os.path.join(GOLDEN, "survey_probe_contrast.json")))
+    ev = make_probe_input(orc)
+    with ebo.Context(loss=ebo.LOSS_EDGE) as c:  # the reference's default loss
+        c.set_patches(ev, [0, len(ev)], [gold["input"]["patch_rect"]])
+        for case in gold["cases"]:
+            r, J = c.eval([case["m"]])
+            assert r[0, 0] == pytest.approx(case["edge_r"], rel=1e-12)
+            np.testing.assert_allclose(J[0, 0], case["edge_J"], rtol=1e-8, atol=1e-14)
+            r1, _ = c.eval([case["m"]], want_jac=False)
+            assert r1[0, 0] == pytest.approx(case["edge_r"], rel=1e-12)
+
+
+@pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 30000)])
+def test_edge_eval_value_and_jacobian(ebo, orc, synth, config, n_events):
+    ev, gt = synth.make_window(config, n_events=n_events)
+    with ctx_for(ebo, synth, config) as c:
+        c.set_window(ev)
+        rng = np.random.RandomState(5 + config)
+        prm = oparams(orc, c.params)
+        for flows in (np.zeros((c.P, 2)), gt * 0.5, rng.uniform(-0.6, 0.6, (c.P, 2))):
+            r, J = c.eval(flows)
+            ro, Jo, active, _ = orc.window_eval(ev, prm, flows)
+            check_rj(r[0], J[0], ro, Jo)
+            r1, _ = c.eval(flows, want_jac=False)
+            np.testing.assert_allclose(r1[0], ro, rtol=1e-9)
+            assert np.all(r[0][active == 0] == 0.0)
+
+
+def test_edge_penalty_branch_and_sparse_images(ebo, orc, synth):
+    """mean(image) <= 1e-4 => 1e3 (1 + |m|^2) (contrast_functor.h:159-165): huge flows, and
+    flows that leave only a handful of events inside the window."""
+    ev, gt = synth.make_window(0, n_events=15000)
+    with ctx_for(ebo, synth, 0) as c:
+        c.set_window(ev)
+        prm = oparams(orc, c.params)
+        for flows in (np.tile([[2.0e3, -3.0e3]], (c.P, 1)), np.tile([[1.6, -1.9]], (c.P, 1)),
+                      np.tile([[3.1, 2.7]], (c.P, 1))):
+            r, J = c.eval(flows)
+            ro, Jo, active, _ = orc.window_eval(ev, prm, flows)
+            check_rj(r[0], J[0], ro, Jo)
+        a = np.nonzero(active)[0][0]
+        assert ro[a] > 1e3  # the penalty branch really was taken
+
+
+def test_edge_global_memory_fallback(ebo, orc, synth, monkeypatch):
+    """Boxes that do not fit LDS use the per-unit global slice: same numbers."""
+    ev, gt = synth.make_window(2, n_events=30000)
+    monkeypatch.setenv("EBO_EDGE_LDS_KB", "24")  # far too small for a 30x22 patch's box
+    with ctx_for(ebo, synth, 2) as c:
+        c.set_window(ev)
+        flows = gt * 0.5
+        r, J = c.eval(flows)
+        ro, Jo, _, _ = orc.window_eval(ev, oparams(orc, c.params), flows)
+        check_rj(r[0], J[0], ro, Jo)
+
+
+def test_edge_central_difference_mode(ebo, orc, synth):
+    ev, gt = synth.make_window(0, n_events=15000)
+    h = 1e-6
+    with ctx_for(ebo, synth, 0, grad=ebo.GRAD_CENTRAL, fd_step=h) as c:
+        c.set_window(ev)
+        flows = gt * 0.4
+        r, J = c.eval(flows)
+        prm = oparams(orc, c.params)
+        ro, _, _, _ = orc.window_eval(ev, prm, flows, want_jac=False)
+        np.testing.assert_allclose(r[0], ro, rtol=1e-9)
+        num = np.zeros((c.P, 2))
+        for k in range(2):
+            d = np.zeros_like(flows)
+            d[:, k] = h
+            rp, _, _, _ = orc.window_eval(ev, prm, flows + d, want_jac=False)
+            rm, _, _, _ = orc.window_eval(ev, prm, flows - d, want_jac=False)
+            num[:, k] = (rp - rm) / (2 * h)
+        np.testing.assert_allclose(J[0], num, rtol=0, atol=2e-6)
+
+
+def test_reference_configuration_end_to_end(ebo, orc, synth):
+    """THE reference call: compensateEventsContrast with every default (edge loss, Jet
+    gradient, TV 1e3 / Huber 10, one global problem, 50 iterations) — flows within 1e-5,
+    same iteration count, final count image bit-exact for the returned flows."""
+    ev, _ = synth.make_window(0, n_events=15000)
+    with ebo.Context() as c:  # all defaults == DetectorParams defaults
+        assert c.params.loss == ebo.LOSS_EDGE
+        flows, img, s = c.compensate_events_contrast(ev)
+        prm = orc.default_params()
+        fo, io, so = orc.compensate_events_contrast(ev, prm, orc.default_solver())
+        err = np.abs(flows - fo).max()
+        assert err <= 1e-5, err
+        assert s.iterations == so.iterations and s.termination == so.termination
+        assert s.final_cost == pytest.approx(so.final_cost, rel=1e-9)
+        assert np.array_equal(img, orc.final_count_image(ev, prm, flows))
+        assert np.abs(img - io).sum() <= 0.002 * len(ev)
+
+
+@pytest.mark.parametrize("iters", [4, 10, 16])
+def test_edge_independent_solve_lockstep(ebo, orc, synth, iters):
+    """Per-patch problems (TV off) with the edge loss: host LMs in lock step, one batched
+    device evaluation per round; capped below the chaos horizon."""
+    ev, _ = synth.make_window(0, n_events=15000)
+    with ctx_for(ebo, synth, 0, tv_weight=0.0) as c:
+        c.set_window(ev)
+        flows, summ = c.solve(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=iters)
+        fo, _, so = orc.compensate_events_contrast(
+            ev, oparams(orc, c.params), orc.default_solver(mode=1, max_num_iterations=iters),
+            want_image=False)
+        err = np.abs(flows[0] - fo).max()
+        assert err <= 1e-5, err
+        assert summ[0].iterations == so.iterations
+        assert summ[0].num_evals_jac == so.num_evals_jac
+        assert summ[0].num_evals_cost == so.num_evals_cost
