@@ -213,6 +213,27 @@ def main():
         torch.cuda.synchronize()
         extras["single_window_eval_us"] = e0.elapsed_time(e1) / 200 * 1e3
         c1.close()
+        # the reference's own default objective (edge / structure-tensor loss), value+Jacobian
+        We = min(Wn, 64)
+        ce = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
+                         patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_EDGE,
+                         tv_weight=0.0, max_events=int(offsets[We]), max_windows=We)
+        ce.set_stream(stream.cuda_stream)
+        ce.set_windows(ev[: int(offsets[We])], offsets[: We + 1])
+        fe = d_flows[:We].contiguous()
+        oe = torch.zeros((We * P, 3), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            ce.eval_device(fe.data_ptr(), 1, oe.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(10):
+            ce.eval_device(fe.data_ptr(), 1, oe.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ems = e0.elapsed_time(e1) / 10
+        extras["edge_loss_value_jacobian"] = {"ms": ems, "windows": We,
+                                              "mevents_per_s": int(offsets[We]) / (ems * 1e-3) / 1e6}
+        ce.close()
 
     if rank == 0:
         base = cpu_baseline(synth, args.config, args.cpu_seconds) if world == 1 else None

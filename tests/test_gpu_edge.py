@@ -70,13 +70,17 @@ def test_edge_penalty_branch_and_sparse_images(ebo, orc, synth):
     with ctx_for(ebo, synth, 0) as c:
         c.set_window(ev)
         prm = oparams(orc, c.params)
+        taken = []
         for flows in (np.tile([[2.0e3, -3.0e3]], (c.P, 1)), np.tile([[1.6, -1.9]], (c.P, 1)),
                       np.tile([[3.1, 2.7]], (c.P, 1))):
             r, J = c.eval(flows)
             ro, Jo, active, _ = orc.window_eval(ev, prm, flows)
             check_rj(r[0], J[0], ro, Jo)
-        a = np.nonzero(active)[0][0]
-        assert ro[a] > 1e3  # the penalty branch really was taken
+            taken.append(int((ro[active == 1] > 1e3).sum()))
+        # huge flow: (nearly) every patch pays the penalty — a patch keeps its image only
+        # if enough of its events sit at dt ~ 0; moderate flows: none does
+        assert taken[0] >= 0.9 * (active == 1).sum()
+        assert taken[1] == 0 and taken[2] == 0
 
 
 def test_edge_global_memory_fallback(ebo, orc, synth, monkeypatch):
@@ -129,10 +133,11 @@ def test_reference_configuration_end_to_end(ebo, orc, synth):
         assert np.abs(img - io).sum() <= 0.002 * len(ev)
 
 
-@pytest.mark.parametrize("iters", [4, 10, 16])
+@pytest.mark.parametrize("iters", [4, 8, 10])
 def test_edge_independent_solve_lockstep(ebo, orc, synth, iters):
     """Per-patch problems (TV off) with the edge loss: host LMs in lock step, one batched
-    device evaluation per round; capped below the chaos horizon."""
+    device evaluation per round; capped below the chaos horizon,
+    which is shorter for the edge loss: its derivative jumps when a window's argmax moves."""
     ev, _ = synth.make_window(0, n_events=15000)
     with ctx_for(ebo, synth, 0, tv_weight=0.0) as c:
         c.set_window(ev)
