@@ -271,8 +271,8 @@ int image_capacity(ebo_ctx* c, int& capDoubles, size_t& lds)
 
 int eval_impl()
 {
-	const int v = static_cast<int>(env_size("EBO_EVAL_IMPL", 2));
-	return (v < 0 || v > 2) ? 2 : v;
+	const int v = static_cast<int>(env_size("EBO_EVAL_IMPL", 3));
+	return (v < 0 || v > 3) ? 3 : v;
 }
 
 int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
@@ -417,19 +417,18 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	else
 	{
 		rc = image_capacity(c, L.cap_doubles, L.lds_bytes);
-		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", 256));
-		if (L.block < 64 || L.block > 1024 || (L.block & 63))
+		// Measured (tools/sweep_impl.py): one row band per unit is best at every batch size
+		// (each band workgroup pays the bounding-box pass over all events); with few units
+		// a 512-thread workgroup shortens the per-unit critical path (29 vs 46 us for one
+		// 64-patch window), with many units 256 threads pack the CU better.
+		const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
+		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : 256));
+		if (L.block < 64 || L.block > 512 || (L.block & 63))
 		{
-			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,1024]");
+			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,512]");
 		}
-		// row bands per unit: one unless there are too few units to fill 256 CUs
-		int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
-		if (t <= 0)
-		{
-			const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
-			t = std::min(8, std::max(1, (1024 + nUnits - 1) / nUnits));
-		}
-		L.tiles = t;
+		const int t = static_cast<int>(env_size("EBO_EVAL_TILES", 1));
+		L.tiles = std::max(1, std::min(t, 64));
 	}
 	if (rc)
 	{
@@ -527,7 +526,7 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
-	L.impl = eval_impl() == 1 ? 1 : 2;
+	L.impl = std::max(1, eval_impl());
 	int rc = image_capacity(c, L.cap_doubles, L.lds_bytes);
 	if (rc)
 	{

@@ -810,20 +810,35 @@ __global__ void k_dump_image(const uint64_t* __restrict__ events, const Unit* __
 // feature_detector.cpp:401-410.  Every thread carries the (uniform) solver state;
 // the objective is evaluated cooperatively.  No host round trips.
 // ---------------------------------------------------------------------------
-template <bool FIXED>
+#include "ebo_eval3.inc"
+
+// FIXED: 1 = impl 1 (f64 atomics), 2 = impl 2, 3 = impl 3 with exp_small, 4 = impl 3
+// with the library exp.
+template <int FIXED>
 __device__ __forceinline__ void eval_unit(const uint64_t* __restrict__ ev, const Unit& u,
 										   double m0, double m1, bool wantJac, int capDoubles,
 										   const EvalConsts& c, double* lds, double& r, double& j0,
 										   double& j1)
 {
 	double S[7];
-	eval_unit2<FIXED, true>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+	if (FIXED == 3)
+	{
+		eval_unit3<true>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+	}
+	else if (FIXED == 4)
+	{
+		eval_unit3<false>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+	}
+	else
+	{
+		eval_unit2<FIXED == 2, false>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+	}
 	j0 = 0.0;
 	j1 = 0.0;
 	variance_from_sums(S, wantJac, m0, m1, c.max_res, r, j0, j1);
 }
 
-template <bool FIXED>
+template <int FIXED>
 __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __restrict__ events,
 									const Unit* __restrict__ units, int capDoubles,
 									double* __restrict__ flowsOut, int32_t* __restrict__ stats,
@@ -1379,6 +1394,17 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
 						   L.d_flows, L.tiles, L.fd_step, L.d_partials, L.d_out, L.c);
 	}
+	else if (L.impl >= 3)
+	{
+		auto kern = (L.c.inv_sigsq <= 1.0) ? k_eval3<true> : k_eval3<false>;
+		if (allow_big_lds(kern, L.lds_bytes))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
+						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
+						   L.d_partials, L.d_out, L.c);
+	}
 	else
 	{
 		auto kern = (L.impl == 2) ? (L.rotate ? k_eval2<true, true> : k_eval2<true, false>)
@@ -1450,7 +1476,11 @@ int launch_solve_independent(const SolveLaunch& L, void* stream)
 	{
 		return 0;
 	}
-	auto kern = (L.impl == 2) ? k_solve_independent<true> : k_solve_independent<false>;
+	const bool smallExp = L.c.inv_sigsq <= 1.0;
+	auto kern = (L.impl == 1)   ? k_solve_independent<1>
+				: (L.impl == 2) ? k_solve_independent<2>
+				: smallExp		? k_solve_independent<3>
+								: k_solve_independent<4>;
 	if (allow_big_lds(kern, L.lds_bytes))
 	{
 		return -2;

@@ -34,7 +34,7 @@ def assert_close(a, b, rtol=RTOL, atol=1e-12):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 50000), (3, 40000)])
+@pytest.mark.parametrize("config,n_events", [(0, 15000), (2, 50000), (3, 40000), (4, 300000)])
 def test_eval_value_and_jacobian(ebo, orc, synth, config, n_events):
     ev, gt = synth.make_window(config, n_events=n_events)
     with ctx_for(ebo, synth, config) as c:
@@ -101,7 +101,7 @@ def test_row_tiling_is_invisible(ebo, orc, synth, tiles, monkeypatch):
         assert_close(J[0], Jo, atol=1e-10)
 
 
-@pytest.mark.parametrize("block", ["64", "512", "1024"])
+@pytest.mark.parametrize("block", ["64", "128", "512"])
 def test_block_size_is_invisible(ebo, orc, synth, block, monkeypatch):
     ev, gt = synth.make_window(0, n_events=15000)
     monkeypatch.setenv("EBO_EVAL_BLOCK", block)
