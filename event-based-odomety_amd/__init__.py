@@ -179,6 +179,16 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def read_events_txt(path, cap=1 << 22):
+    """DAVIS240C events.txt -> structured event array (host-side parser of the library)."""
+    out = np.zeros(cap, dtype=EVENT_DTYPE)
+    n = C.c_size_t()
+    rc = lib().ebo_read_events_txt(str(path).encode(), _vp(out), C.c_size_t(cap), C.byref(n))
+    if rc:
+        raise EboError(rc, "cannot parse %s (parsed %d events before the error)" % (path, n.value))
+    return out[: n.value].copy()
+
+
 def make_events(x, y, t_us, sign=None):
     ev = np.zeros(len(x), dtype=EVENT_DTYPE)
     ev["x"] = x

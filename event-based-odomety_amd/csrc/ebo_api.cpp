@@ -1769,6 +1769,99 @@ int ebo_patch_integrate_mc(ebo_ctx* c, const ebo_event* ev, const size_t* offset
 								  nabla, nullptr, nullptr, updated);
 }
 
+// DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one
+// event per line "<seconds> <x> <y> <0|1>".  Seconds go through a double and are
+// truncated to microseconds, exactly as std::stod + duration_cast do there.
+int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
+{
+	if (!path || !n || (cap && !out))
+	{
+		return EBO_ERR_ARG;
+	}
+	*n = 0;
+	FILE* fp = std::fopen(path, "rb");
+	if (!fp)
+	{
+		return EBO_ERR_ARG;
+	}
+	std::vector<char> buf(1 << 20);
+	std::string line;
+	size_t count = 0;
+	int rc = EBO_OK;
+	auto take = [&](const std::string& ln) -> bool {
+		const char* s = ln.c_str();
+		char* end = nullptr;
+		const double sec = std::strtod(s, &end);
+		if (end == s)
+		{
+			return true;  // blank line
+		}
+		const char* p = end;
+		const long x = std::strtol(p, &end, 10);
+		if (end == p)
+		{
+			rc = EBO_ERR_RANGE;
+			return false;
+		}
+		p = end;
+		const long y = std::strtol(p, &end, 10);
+		if (end == p)
+		{
+			rc = EBO_ERR_RANGE;
+			return false;
+		}
+		p = end;
+		const long sign = std::strtol(p, &end, 10);
+		if (end == p || (sign != 0 && sign != 1))
+		{
+			rc = EBO_ERR_RANGE;  // "Sign is not equal to 0/1" (:85-88)
+			return false;
+		}
+		if (count >= cap)
+		{
+			return false;
+		}
+		ebo_event& e = out[count++];
+		e.x = static_cast<int32_t>(x);
+		e.y = static_cast<int32_t>(y);
+		e.sign = sign == 0 ? -1 : 1;
+		e.reserved = 0;
+		e.t_us = static_cast<int64_t>(sec * 1000000.0);
+		return true;
+	};
+	bool go = true;
+	while (go)
+	{
+		const size_t got = std::fread(buf.data(), 1, buf.size(), fp);
+		if (got == 0)
+		{
+			break;
+		}
+		size_t start = 0;
+		for (size_t i = 0; i < got && go; ++i)
+		{
+			if (buf[i] == '\n')
+			{
+				line.append(buf.data() + start, i - start);
+				go = take(line);
+				line.clear();
+				start = i + 1;
+			}
+		}
+		if (go)
+		{
+			line.append(buf.data() + start, got - start);
+		}
+	}
+	if (go && !line.empty())
+	{
+		take(line);
+	}
+	std::fclose(fp);
+	*n = count;
+	return rc;
+}
+
 int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end)
 {
 	if (n_units < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end)

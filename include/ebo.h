@@ -219,6 +219,12 @@ int ebo_patch_integrate_mc(ebo_ctx* ctx, const ebo_event* ev, const size_t* offs
 						   const int64_t* mid_time, const size_t* nabla_offsets,
 						   double* nabla, int32_t* updated);
 
+/* DAVIS240C events.txt reader, Davis240cReader::getEventSample
+ * (tools/dataset_reader/src/davis240c_reader.cpp:60-92): "<seconds> <x> <y> <0|1>" per
+ * line -> out[0..*n), at most cap events.  Host only; EBO_ERR_RANGE on a malformed line or a
+ * sign other than 0/1 (the reference throws there), events parsed before it are kept. */
+int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n);
+
 /* Contiguous shard [begin,end) of n_units for rank of world (multi-GPU, §8e). */
 int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end);
 

@@ -11,6 +11,7 @@
 #include "../../event-based-odomety_amd/include/feature_tracker/contrast_functor.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/feature_detector.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/total_variance.h"
+#include "../../event-based-odomety_amd/include/tools/event_pump.h"
 #include "../../oracle/ebo_oracle.h"
 
 static int g_fail = 0;
@@ -231,6 +232,42 @@ int main()
 	tracker::contrastFunctor bad(far, rect, params.compensateScale, EBO_LOSS_VARIANCE);
 	double rr = 0;
 	EXPECT_TRUE(!bad(motions[0], &rr));
+
+	// ---- EventPump: events.txt -> reader -> evaluator's window rule -> detector --------------
+	{
+		const char* path = "/tmp/ebo_facade_events.txt";
+		FILE* fp = std::fopen(path, "w");
+		for (const auto& s : samples)
+		{
+			std::fprintf(fp, "%.9f %d %d %d\n", s.timestamp.count() * 1e-6, s.value.point.x, s.value.point.y,
+						 s.value.sign == common::POSITIVE ? 1 : 0);
+		}
+		std::fclose(fp);
+		const auto read = tools::EventPump::readEvents(path);
+		EXPECT_TRUE(read.size() == samples.size());
+		EXPECT_TRUE(read[777].value.point.x == samples[777].value.point.x);
+		EXPECT_TRUE(read[777].value.sign == samples[777].value.sign);
+		tracker::DetectorParams p2;
+		p2.loss = EBO_LOSS_VARIANCE;
+		tracker::FeatureDetector det2(p2);
+		tools::EventPump pump(det2);
+		size_t seen = 0, lastN = 0;
+		pump.onWindow([&](tracker::FeatureDetector& d, size_t n) {
+			++seen;
+			lastN = n;
+			double s = 0;
+			for (int i = 0; i < 240 * 180; ++i)
+			{
+				s += d.getIntegratedEventImage().ptr()[i];
+			}
+			EXPECT_TRUE(s == static_cast<double>(n));
+		});
+		pump.replay(read);
+		// t starts at 100 ms: the first event is not yet 300 ms past lastCompensation = 0, so the
+		// first window closes at 15000 events; the remaining 5000 events stay pending
+		EXPECT_TRUE(pump.windows() == 1 && seen == 1 && lastN == 15000);
+		EXPECT_TRUE(det2.getEvents().size() == 5000);
+	}
 
 	std::printf(g_fail ? "facade_test: %d FAILED\n" : "facade_test: all passed\n", g_fail);
 	return g_fail ? 1 : 0;

@@ -1,0 +1,101 @@
+"""BASELINE config 1 (plumbing): a 240x180 stream as a DAVIS events.txt, read back,
+pumped through the evaluator's window rule (tools/evaluator/src/evaluator.cpp:32-45: compensate when
+>= 300000 us since the last compensation or >= 15000 events), ONE patch = the whole frame
+(patchCompensateSize = imageSize), 10k-event windows.  The CPU leg uses the oracle (the reference's
+CPU path); the GPU leg runs the same file through the HIP path."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def window_rule(ev, freq_time=300000, freq_events=15000):
+    """Evaluator::eventCallback's trigger, returning [begin, end) index ranges of the windows."""
+    out, begin, last_comp = [], 0, 0
+    for i in range(len(ev)):
+        n = i + 1 - begin
+        if int(ev["t_us"][i]) - last_comp >= freq_time or n >= freq_events:
+            out.append((begin, i + 1))
+            last_comp = int(ev["t_us"][i])  # lastCompensation = events.back().timestamp (:307)
+            begin = i + 1
+    return out
+
+
+@pytest.fixture(scope="module")
+def stream_file(tmp_path_factory, synth):
+    cfg = dict(synth.CONFIGS[1], index=1)
+    evs = []
+    for w in range(3):
+        e, _ = synth.make_window(cfg, window=w, n_events=10000, vmax=0.3)
+        evs.append(e)
+    ev = np.concatenate(evs)
+    path = tmp_path_factory.mktemp("davis") / "events.txt"
+    synth.write_events_txt(str(path), ev)
+    return str(path), ev
+
+
+def test_events_txt_round_trip_and_reader_fixture(ebo, orc, stream_file):
+    path, ev = stream_file
+    got = ebo.read_events_txt(path)
+    rc, ref = orc.parse_events_txt(path)
+    assert rc == 0
+    assert np.array_equal(got, ref)  # product parser == oracle parser, every field
+    assert np.array_equal(got["x"], ev["x"]) and np.array_equal(got["y"], ev["y"])
+    assert np.array_equal(got["sign"], ev["sign"])
+    assert np.abs(got["t_us"] - ev["t_us"]).max() <= 1  # %.9f seconds -> double -> truncation
+    # the reference's own reader fixture (davis240c_reader_test.cpp:19-48)
+    fx = ebo.read_events_txt(os.path.join(HERE, "golden", "davis_events_fixture.txt"))
+    assert fx["x"].tolist() == [33, 158, 88, 174, 112]
+    assert fx["y"].tolist() == [39, 145, 143, 154, 139]
+    assert fx["sign"].tolist() == [1, 1, -1, -1, 1]
+    assert fx["t_us"].tolist() == [0, 11, 50, 55, 80]
+
+
+def test_reader_rejects_bad_sign(ebo, tmp_path):
+    p = tmp_path / "events.txt"
+    p.write_text("0.000001 1 2 1\n0.000002 3 4 7\n")
+    with pytest.raises(ebo.EboError) as ei:
+        ebo.read_events_txt(str(p))
+    assert ei.value.code == ebo.ERR_RANGE
+
+
+def test_config1_cpu_reference_path(ebo, orc, stream_file):
+    """CPU only: reader -> window rule -> oracle compensateEventsContrast + integrateEvents."""
+    path, _ = stream_file
+    ev = ebo.read_events_txt(path)
+    wins = window_rule(ev)
+    # the stream starts at t = 1 s: the very first event is already 300 ms past lastCompensation = 0
+    assert wins[0] == (0, 1)
+    assert [b - a for a, b in wins[1:]] == [15000]  # then the 15000-event cap triggers once
+    prm = orc.default_params(patch_w=240, patch_h=180, loss=1)
+    assert orc.grid(prm) == (1, 1)
+    a, b = wins[1]
+    flows, img, s = orc.compensate_events_contrast(ev[a:b], prm, orc.default_solver(max_num_iterations=8))
+    assert flows.shape == (1, 2) and np.isfinite(flows).all()
+    assert s.final_cost <= s.initial_cost
+    assert img.sum() <= b - a
+    assert orc.integrate_events(ev[a:b], 240, 180).sum() == b - a
+    # a one-event window has no data term (1 <= compensateMinNumEvents): flows stay 0
+    f0, _, s0 = orc.compensate_events_contrast(ev[0:1], prm, orc.default_solver())
+    assert np.all(f0 == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", [1, 0])
+def test_config1_through_the_hip_path(ebo, orc, stream_file, loss):
+    path, _ = stream_file
+    ev = ebo.read_events_txt(path)
+    a, b = window_rule(ev)[1]
+    iters = 8
+    with ebo.Context(patch_w=240, patch_h=180, loss=loss, max_events=15000) as c:
+        assert (c.npx, c.npy) == (1, 1)
+        flows, img, s = c.compensate_events_contrast(ev[a:b], ebo.default_solver(max_num_iterations=iters))
+        prm = orc.default_params(patch_w=240, patch_h=180, loss=loss)
+        fo, io, so = orc.compensate_events_contrast(ev[a:b], prm, orc.default_solver(max_num_iterations=iters))
+        assert np.abs(flows - fo).max() <= 1e-5
+        assert s.iterations == so.iterations
+        assert np.array_equal(img, orc.final_count_image(ev[a:b], prm, flows))
+        integ = c.count_image(ebo.COUNT_INTEGRATED)[0]
+        assert np.array_equal(integ, orc.integrate_events(ev[a:b], 240, 180))
