@@ -244,7 +244,7 @@ def main():
         if os.path.exists(tpath):
             t = json.load(open(tpath))
             if t.get("workload") == cfg["name"] and t.get("windows") == Wn:
-                traffic = t.get("k_eval2_hbm_bytes_per_launch")
+                traffic = t.get("eval_kernel_hbm_bytes_per_launch")
         value = total_events * args.steps / dt / 1e6
         line = {
             "metric": "Mevents/s warped+scored (value+Jacobian of the variance-contrast objective)",
@@ -258,7 +258,7 @@ def main():
                            world, ", RCCL all-gather of (r,J) per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_eval2<true,true>", "kernel_ms": kern_ms,
+                         "kernel": "k_eval3<true>", "kernel_ms": kern_ms,
                          "note": "algorithmic 8 B/event-evaluation; the kernel is bound by LDS "
                                  "atomics + f64 VALU, not HBM (DESIGN.md section 4)"},
             "cpu_baseline": base,
