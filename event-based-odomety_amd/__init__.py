@@ -260,6 +260,14 @@ class Context:
         self.n_windows = n
         self._custom = None
 
+    def set_windows_device(self, d_events, offsets):
+        """Raw ebo_event records already in device memory (pointer as int); offsets: host."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        self._check(lib().ebo_set_windows_device(self._h, C.c_void_p(int(d_events)), _vp(offsets), int(n)))
+        self.n_windows = n
+        self._custom = None
+
     def set_patches(self, ev, offsets, rects):
         """Arbitrary patches (contrastFunctor instances): rects [n][4] = (x, y, w, h)."""
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)

@@ -66,6 +66,9 @@ struct ebo_ctx
 	size_t scratch_cap = 0;
 	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
 	size_t edge_scratch_cap = 0;
+	void* d_raw = nullptr;           // raw 24-byte events staged for device bucketing
+	void* d_bucket = nullptr;        // bucketing scratch
+	size_t bucket_cap = 0;
 
 	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window
 	std::vector<int64_t> unit_tref;
@@ -1005,6 +1008,8 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_stats);
 	hipFree(c->d_scratch);
 	hipFree(c->d_edge_scratch);
+	hipFree(c->d_raw);
+	hipFree(c->d_bucket);
 	if (c->ev0) hipEventDestroy(c->ev0);
 	if (c->ev1) hipEventDestroy(c->ev1);
 	if (c->own_stream && c->stream)
@@ -1060,7 +1065,191 @@ int ebo_patch_rect(const ebo_ctx* c, int px, int py, int* x, int* y, int* w, int
 	return EBO_OK;
 }
 
+// Bucketing + packing on the device (ebo_bucket.inc).  d_raw: ebo_event[] on the device,
+// offsets: host, absolute indices into d_raw.
+static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* offsets, int n_windows)
+{
+	const size_t total = offsets[n_windows] - offsets[0];
+	const int P = c->P;
+	const size_t nUnits = static_cast<size_t>(n_windows) * (P + 1);
+	size_t maxWin = 0;
+	std::vector<unsigned long long> off64(n_windows + 1);
+	for (int w = 0; w <= n_windows; ++w)
+	{
+		off64[w] = offsets[w];
+		if (w && offsets[w] < offsets[w - 1])
+		{
+			return c->fail(EBO_ERR_ARG, "offsets must be non-decreasing");
+		}
+		if (w)
+		{
+			maxWin = std::max(maxWin, offsets[w] - offsets[w - 1]);
+		}
+	}
+	(void)hipSetDevice(c->prm.device);
+	// one scratch block: offsets | cnt | tmin | tmax | unit tref | window tref | flag
+	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+	const size_t bOff = al((n_windows + 1) * 8), bCnt = al(nUnits * 4), bT = al(nUnits * 8), bW = al(n_windows * 8);
+	const size_t need = bOff + bCnt + 3 * bT + bW + 256;
+	if (need > c->bucket_cap)
+	{
+		if (c->d_bucket)
+		{
+			hipFree(c->d_bucket);
+			c->d_bucket = nullptr;
+			c->bucket_cap = 0;
+		}
+		int rc = c->hip(hipMalloc(&c->d_bucket, need), "hipMalloc bucket scratch");
+		if (rc)
+		{
+			return rc;
+		}
+		c->bucket_cap = need;
+	}
+	char* base = static_cast<char*>(c->d_bucket);
+	BucketLaunch L;
+	L.d_raw = d_raw;
+	L.d_offsets = reinterpret_cast<unsigned long long*>(base);
+	L.d_cnt = reinterpret_cast<int*>(base + bOff);
+	L.d_tmin = reinterpret_cast<long long*>(base + bOff + bCnt);
+	L.d_tmax = reinterpret_cast<long long*>(base + bOff + bCnt + bT);
+	L.d_unit_tref = reinterpret_cast<long long*>(base + bOff + bCnt + 2 * bT);
+	L.d_win_tref = reinterpret_cast<long long*>(base + bOff + bCnt + 3 * bT);
+	L.d_flag = reinterpret_cast<int*>(base + bOff + bCnt + 3 * bT + bW);
+	L.n_windows = n_windows;
+	L.P = P;
+	L.max_chunks = static_cast<int>((maxWin + 2047) / 2048);
+	L.min_events = c->prm.min_events;
+	L.d_units = c->d_units;
+	L.d_packed = c->d_events;
+	L.c = make_consts(c);
+	int rc = c->hip(hipMemcpyAsync(const_cast<unsigned long long*>(L.d_offsets), off64.data(), off64.size() * 8,
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D offsets");
+	if (rc)
+	{
+		return rc;
+	}
+	if (launch_bucket(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "bucket launch");
+	}
+	std::vector<Unit> units(nUnits);
+	std::vector<int64_t> utref(nUnits);
+	std::vector<long long> wtref(n_windows);
+	int flag = 0;
+	hipError_t e = hipMemcpyAsync(units.data(), c->d_units, nUnits * sizeof(Unit), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(utref.data(), L.d_unit_tref, nUnits * 8, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(wtref.data(), L.d_win_tref, n_windows * 8, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(&flag, L.d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess)
+	{
+		c->n_windows = 0;
+		return c->hip(e, "bucket results");
+	}
+	if (flag)
+	{
+		c->n_windows = 0;
+		c->custom_n = 0;
+		return c->fail(EBO_ERR_RANGE,
+					   (flag & 1)	? "event coordinate outside [-16384,16383]"
+					   : (flag & 2) ? "mid-time outside int32 microseconds (undefined in the reference)"
+									: "event time further than 2^31 us from the reference time");
+	}
+	std::vector<WindowInfo> wins(n_windows);
+	for (int w = 0; w < n_windows; ++w)
+	{
+		wins[w].t_ref = wtref[w];
+		wins[w].n_events = offsets[w + 1] - offsets[w];
+	}
+	(void)total;
+	c->units.swap(units);
+	c->unit_tref.swap(utref);
+	c->windows.swap(wins);
+	c->n_windows = n_windows;
+	c->custom_n = 0;
+	c->max_rw = c->grid_max_rw;
+	c->max_rh = c->grid_max_rh;
+	return EBO_OK;
+}
+
+int ebo_set_windows_device(ebo_ctx* c, const ebo_event* d_ev, const size_t* offsets, int n_windows)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!d_ev || !offsets || n_windows <= 0)
+	{
+		return c->fail(EBO_ERR_ARG, "null events/offsets or no window");
+	}
+	if (n_windows > c->cap_windows)
+	{
+		return c->fail(EBO_ERR_ARG, "more windows than max_windows");
+	}
+	if (offsets[n_windows] - offsets[0] > c->cap_events)
+	{
+		return c->fail(EBO_ERR_ARG, "more events than max_events");
+	}
+	return set_windows_on_device(c, d_ev, offsets, n_windows);
+}
+
+static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_windows);
+
 int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_windows)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!offsets || n_windows <= 0 || (!ev && offsets[n_windows] > offsets[0]))
+	{
+		return c->fail(EBO_ERR_ARG, "null events/offsets or no window");
+	}
+	if (n_windows > c->cap_windows)
+	{
+		return c->fail(EBO_ERR_ARG, "more windows than max_windows");
+	}
+	const size_t total = offsets[n_windows] - offsets[0];
+	if (total > c->cap_events)
+	{
+		return c->fail(EBO_ERR_ARG, "more events than max_events");
+	}
+	const char* mode = std::getenv("EBO_BUCKET");
+	if (mode && std::strcmp(mode, "host") == 0)
+	{
+		return set_windows_host(c, ev, offsets, n_windows);
+	}
+	// default: raw events go to the device once; bucketing and packing happen there
+	(void)hipSetDevice(c->prm.device);
+	if (!c->d_raw)
+	{
+		int rc = c->hip(hipMalloc(&c->d_raw, c->cap_events * sizeof(ebo_event)), "hipMalloc raw events");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	if (total > 0)
+	{
+		int rc = c->hip(hipMemcpyAsync(c->d_raw, ev + offsets[0], total * sizeof(ebo_event),
+									   hipMemcpyHostToDevice, c->stream),
+						"H2D raw events");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	std::vector<size_t> rel(n_windows + 1);
+	for (int w = 0; w <= n_windows; ++w)
+	{
+		rel[w] = offsets[w] - offsets[0];
+	}
+	return set_windows_on_device(c, c->d_raw, rel.data(), n_windows);
+}
+
+static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_windows)
 {
 	if (!c)
 	{

@@ -162,6 +162,27 @@ struct CountLaunch
 };
 int launch_count_image(const CountLaunch& L, void* stream);
 
+// Device-side bucketing of raw 24-byte events (ebo_bucket.inc).
+struct BucketLaunch
+{
+	const void* d_raw;                 // ebo_event[] on the device
+	const unsigned long long* d_offsets; // [n_windows + 1], absolute indices into d_raw
+	int n_windows;
+	int P;
+	int max_chunks;                    // ceil(max events per window / 2048)
+	unsigned int min_events;
+	int* d_cnt;                        // [n_windows][P+1] scratch (counts, then cursors)
+	long long* d_tmin;                 // [n_windows][P+1]
+	long long* d_tmax;
+	Unit* d_units;                     // out [n_windows][P+1]
+	long long* d_unit_tref;            // out [n_windows][P+1]
+	long long* d_win_tref;             // out [n_windows]
+	uint64_t* d_packed;                // out packed events
+	int* d_flag;                       // out error bits
+	EvalConsts c;
+};
+int launch_bucket(const BucketLaunch& L, void* stream);
+
 struct PatchIntLaunch
 {
 	const uint64_t* d_events;  // packed, dt = mid_time - t

@@ -1354,6 +1354,7 @@ __global__ void k_patch_integrate(const uint64_t* __restrict__ events,
 }
 
 #include "ebo_edge.inc"
+#include "ebo_bucket.inc"
 
 int check_launch()
 {
@@ -1426,6 +1427,47 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		hipLaunchKernelGGL(k_combine_variance, dim3((L.n_units + 127) / 128), dim3(128), 0, s,
 						   L.d_units, L.n_units, L.d_flows, L.tiles, L.flow_sets, L.channels,
 						   L.fd_step, L.d_partials, L.d_out, L.c);
+	}
+	return check_launch();
+}
+
+int launch_bucket(const BucketLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const int nUnits = L.n_windows * (L.P + 1);
+	const RawEvent* raw = static_cast<const RawEvent*>(L.d_raw);
+	hipLaunchKernelGGL(k_bucket_init, dim3((nUnits + 255) / 256), dim3(256), 0, s, L.d_cnt, L.d_tmin,
+					   L.d_tmax, nUnits, L.d_flag);
+	if (check_launch())
+	{
+		return -2;
+	}
+	const size_t lds = static_cast<size_t>(L.P + 1) * (2 * sizeof(long long) + sizeof(int)) + 8;
+	if (L.max_chunks > 0)
+	{
+		if (allow_big_lds(k_bucket_count, lds))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(k_bucket_count, dim3(L.max_chunks, L.n_windows), dim3(256), lds, s, raw,
+						   L.d_offsets, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.c);
+		if (check_launch())
+		{
+			return -2;
+		}
+	}
+	hipLaunchKernelGGL(k_bucket_scan, dim3((L.n_windows + 63) / 64), dim3(64), 0, s, raw, L.d_offsets,
+					   L.n_windows, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.min_events, L.d_units,
+					   L.d_unit_tref, L.d_win_tref, L.d_flag, L.c);
+	if (check_launch())
+	{
+		return -2;
+	}
+	if (L.max_chunks > 0)
+	{
+		hipLaunchKernelGGL(k_bucket_scatter, dim3(L.max_chunks, L.n_windows), dim3(256), 0, s, raw,
+						   L.d_offsets, L.P, L.d_cnt, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
+						   L.d_flag, L.c);
 	}
 	return check_launch();
 }

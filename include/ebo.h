@@ -158,6 +158,12 @@ int ebo_patch_rect(const ebo_ctx* ctx, int px, int py, int* x, int* y, int* w, i
 int ebo_set_window(ebo_ctx* ctx, const ebo_event* ev, size_t n);
 /* Batch of independent windows: window w = ev[offsets[w] .. offsets[w+1]). */
 int ebo_set_windows(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets, int n_windows);
+/* Same with the raw events already on the device (d_ev: ebo_event[] in device memory,
+ * offsets: host, indices into d_ev): bucketing, reference times and packing all run on
+ * the device; nothing but the 28-byte-per-patch table comes back.  ebo_set_window(s)
+ * uses this path after one H2D copy of the raw events (EBO_BUCKET=host selects the host
+ * counting sort instead). */
+int ebo_set_windows_device(ebo_ctx* ctx, const ebo_event* d_ev, const size_t* offsets, int n_windows);
 /* Arbitrary patches instead of a window: patch i = cv::Rect2i rects[i][4] = (x,y,w,h)
  * with its own event list ev[offsets[i]..offsets[i+1]) in list order, exactly what
  * tracker::contrastFunctor's constructor takes (contrast_functor.h:12-21; events

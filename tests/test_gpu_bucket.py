@@ -1,0 +1,90 @@
+"""GPU tests of the device-side bucketing: the unit table and every
+downstream result are identical to the host counting sort's (EBO_BUCKET=host), and to the
+oracle's literal O(P*N) per-patch scan (feature_detector.cpp:348-355)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def build(ebo, synth, config, ev, offsets, **kw):
+    cfg = synth.CONFIGS[config]
+    c = ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                    patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE, max_windows=len(offsets) - 1,
+                    max_events=len(ev), **kw)
+    return c
+
+
+@pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 5, 20000), (4, 2, 150000)])
+def test_device_bucketing_equals_host_bucketing(ebo, orc, synth, monkeypatch, config, n_windows, n_events):
+    ev, offsets, gt = synth.make_stream(config, n_windows, n_events=n_events)
+    ev["x"][3] = -2  # strays
+    ev["y"][11] = 30000 // 2
+    results = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("EBO_BUCKET", mode)
+        with build(ebo, synth, config, ev, offsets) as c:
+            c.set_windows(ev, offsets)
+            info = [[c.patch_info(p, w) for p in range(c.P)] for w in range(n_windows)]
+            wins = [c.window_info(w) for w in range(n_windows)]
+            r, J = c.eval(gt * 0.5)
+            img = c.count_image(ebo.COUNT_WARPED, gt * 0.7)
+            integ = c.count_image(ebo.COUNT_INTEGRATED)
+            results[mode] = (info, wins, r, J, img, integ)
+    h, d = results["host"], results["device"]
+    assert h[0] == d[0]  # per-patch counts, active flags, reference times
+    assert h[1] == d[1]  # per-window reference times and sizes
+    # exact fixed-point accumulation: the order inside a unit does not matter, bit for bit
+    assert np.array_equal(h[2], d[2]) and np.array_equal(h[3], d[3])
+    assert np.array_equal(h[4], d[4]) and np.array_equal(h[5], d[5])
+    # and both equal the oracle's literal scan
+    cfg = synth.CONFIGS[config]
+    prm = orc.default_params(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                             patch_h=cfg["patch"][1], loss=1)
+    sub = ev[int(offsets[0]):int(offsets[1])]
+    ro, Jo, active, counts = orc.window_eval(sub, prm, gt[0] * 0.5)
+    assert [i[0] for i in d[0][0]] == counts.tolist()
+    np.testing.assert_allclose(d[2][0], ro, rtol=1e-9)
+
+
+def test_device_resident_raw_events(ebo, orc, synth):
+    """ebo_set_windows_device: the raw 24-byte records never touch the host path."""
+    import torch
+    ev, offsets, gt = synth.make_stream(2, 4, n_events=25000)
+    raw = torch.from_numpy(ev.view(np.uint8).reshape(-1, 24).copy()).to("cuda")
+    with build(ebo, synth, 2, ev, offsets) as c:
+        c.set_windows_device(raw.data_ptr(), offsets)
+        r, J = c.eval(gt * 0.5)
+        prm = orc.default_params(patch_w=30, patch_h=22, loss=1)
+        for w in range(4):
+            sub = ev[int(offsets[w]):int(offsets[w + 1])]
+            ro, Jo, _, _ = orc.window_eval(sub, prm, gt[w] * 0.5)
+            np.testing.assert_allclose(r[w], ro, rtol=1e-9)
+            np.testing.assert_allclose(J[w], Jo, rtol=1e-9, atol=1e-10)
+            assert c.window_info(w) == (orc.mid_timestamp(sub["t_us"][0], sub["t_us"][-1]), len(sub))
+        # a sub-range of the device buffer (offsets need not start at 0)
+        c.set_windows_device(raw.data_ptr(), offsets[1:3])
+        r1, _ = c.eval(gt[1:2] * 0.5)
+        np.testing.assert_array_equal(r1[0], r[1])
+
+
+def test_device_bucketing_error_flags(ebo, synth):
+    ev, _ = synth.make_window(0, n_events=3000)
+    with ebo.Context(loss=ebo.LOSS_VARIANCE) as c:
+        bad = ev.copy()
+        bad["y"][7] = -20000
+        with pytest.raises(ebo.EboError) as ei:
+            c.set_window(bad)
+        assert ei.value.code == ebo.ERR_RANGE and "coordinate" in str(ei.value)
+        far = ev.copy()
+        far["t_us"][-1] += 1 << 33
+        with pytest.raises(ebo.EboError) as ei:
+            c.set_window(far)
+        assert ei.value.code == ebo.ERR_RANGE
+        late = ev.copy()
+        late["t_us"] += 1 << 32  # mid time beyond int32: undefined in the reference
+        with pytest.raises(ebo.EboError) as ei:
+            c.set_window(late)
+        assert ei.value.code == ebo.ERR_RANGE and "int32" in str(ei.value)
+        c.set_window(ev)
+        assert c.eval(np.zeros((c.P, 2)))[0].shape == (1, c.P)
