@@ -213,6 +213,26 @@ def main():
         torch.cuda.synchronize()
         extras["single_window_eval_us"] = e0.elapsed_time(e1) / 200 * 1e3
         c1.close()
+        # window set-up: host counting sort + 8 B/event upload  vs  24 B/event upload + device
+        # bucketing  vs  device bucketing of events already resident (ebo_set_windows_device)
+        t0 = time.perf_counter()
+        os.environ["EBO_BUCKET"] = "host"
+        ctx.set_windows(ev, offsets)
+        t_host = time.perf_counter() - t0
+        os.environ.pop("EBO_BUCKET")
+        t0 = time.perf_counter()
+        ctx.set_windows(ev, offsets)
+        t_dev = time.perf_counter() - t0
+        d_raw = torch.from_numpy(ev.view(np.uint8).reshape(-1, 24)).to("cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.set_windows_device(d_raw.data_ptr(), offsets)
+        t_res = time.perf_counter() - t0
+        extras["window_setup_mevents_per_s"] = {
+            "host_bucketing_plus_upload": n_events / t_host / 1e6,
+            "raw_upload_plus_device_bucketing": n_events / t_dev / 1e6,
+            "device_bucketing_resident_events": n_events / t_res / 1e6}
+        del d_raw
         # the reference's own default objective (edge / structure-tensor loss), value+Jacobian
         We = min(Wn, 64)
         ce = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],

@@ -1373,6 +1373,16 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 								 (static_cast<uint64_t>(static_cast<uint32_t>(static_cast<int32_t>(dt))) << 32);
 			c->h_packed[base + cur[b]++] = rec;
 		}
+		// canonical order inside a unit (as k_bucket_sort): both bucketing paths then
+		// hand identical arrays to the kernels
+		for (int b = 0; b <= P; ++b)
+		{
+			const Unit& u = units[static_cast<size_t>(w) * (P + 1) + b];
+			if (u.n_ev >= 2 && u.n_ev <= 8192)
+			{
+				std::sort(c->h_packed.begin() + u.ev_off, c->h_packed.begin() + u.ev_off + u.n_ev);
+			}
+		}
 		base += n;
 	}
 	(void)hipSetDevice(c->prm.device);

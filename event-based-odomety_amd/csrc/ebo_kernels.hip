@@ -1468,6 +1468,16 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 		hipLaunchKernelGGL(k_bucket_scatter, dim3(L.max_chunks, L.n_windows), dim3(256), 0, s, raw,
 						   L.d_offsets, L.P, L.d_cnt, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
 						   L.d_flag, L.c);
+		if (check_launch())
+		{
+			return -2;
+		}
+		const size_t sortLds = static_cast<size_t>(kSortMax) * sizeof(unsigned long long);
+		if (allow_big_lds(k_bucket_sort, sortLds))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(k_bucket_sort, dim3(nUnits), dim3(256), sortLds, s, L.d_units, L.d_packed);
 	}
 	return check_launch();
 }

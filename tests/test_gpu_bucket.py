@@ -49,9 +49,19 @@ def test_device_bucketing_equals_host_bucketing(ebo, orc, synth, monkeypatch, co
 
 def test_device_resident_raw_events(ebo, orc, synth):
     """ebo_set_windows_device: the raw 24-byte records never touch the host path."""
-    import torch
+    import ctypes
     ev, offsets, gt = synth.make_stream(2, 4, n_events=25000)
-    raw = torch.from_numpy(ev.view(np.uint8).reshape(-1, 24).copy()).to("cuda")
+    # device buffer through the HIP runtime the library itself uses (no second runtime)
+    hip = ctypes.CDLL("libamdhip64.so")
+    d_raw = ctypes.c_void_p()
+    host = np.ascontiguousarray(ev)
+    assert hip.hipMalloc(ctypes.byref(d_raw), ctypes.c_size_t(host.nbytes)) == 0
+    assert hip.hipMemcpy(d_raw, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(host.nbytes), 1) == 0
+
+    class _Raw:
+        def data_ptr(self):
+            return d_raw.value
+    raw = _Raw()
     with build(ebo, synth, 2, ev, offsets) as c:
         c.set_windows_device(raw.data_ptr(), offsets)
         r, J = c.eval(gt * 0.5)
