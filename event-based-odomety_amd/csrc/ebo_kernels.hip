@@ -879,7 +879,9 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 			double seAccRef = 0.0, seAccCand = 0.0;
 			int seNumNonmono = 0;
 			double radius = o.initial_radius, decreaseFactor = 2.0;
-			bool reuseDiagonal = false, lastSuccessful = false;
+			// iteration zero counts as successful: a start already within the gradient
+			// tolerance converges immediately
+			bool reuseDiagonal = false, lastSuccessful = true;
 			double d0 = 0.0, d1 = 0.0;
 			int numInvalid = 0;
 

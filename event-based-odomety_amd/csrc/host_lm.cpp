@@ -443,6 +443,9 @@ void HostLm::supply(const double* r, const double* J)
 		afterJacobian();
 		xNorm_ = 0.0;
 		seMin_ = seCur_ = seRef_ = seCand_ = xCost_;
+		// iteration zero counts as successful: a start already within the gradient
+		// tolerance converges immediately ("Gradient tolerance reached")
+		lastSuccessful_ = true;
 		advance();
 		return;
 	}

@@ -769,7 +769,10 @@ int minimize(Problem& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 
 	int iteration = 0;
 	int numInvalid = 0;
-	bool lastSuccessful = false;
+	// Iteration zero counts as a successful evaluation point: a start that already
+	// satisfies the gradient tolerance terminates with CONVERGENCE (Ceres: "Gradient
+	// tolerance reached"), e.g. TV terms only at the all-zero start.
+	bool lastSuccessful = true;
 	int termination = 1;
 
 	// Band of the normal equations.

@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH = os.environ.get("EBO_ORACLE_LIB", os.path.join(ORACLE_DIR, "liboracle.so"))
 
 # numpy mirror of orc_event / ebo_event / common::EventSample (24 bytes)
 EVENT_DTYPE = np.dtype(

@@ -1,0 +1,83 @@
+"""CPU test of the PRODUCT's host trust-region solver (csrc/host_lm.cpp) without a GPU: the
+data-term residuals/Jacobians it asks for are supplied by the oracle instead of the device, and
+the outcome is compared with the oracle's own solver on the reference's problem (data + TV terms,
+feature_detector.cpp:316-414).  Same evaluations in, so the flows agree to rounding of the
+linear algebra (banded vs dense Cholesky)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPP = os.path.join(HERE, "cpp")
+
+
+@pytest.fixture(scope="module")
+def shim(ebo):
+    subprocess.check_call(["make", "-s", "-C", CPP, "libhostlm_shim.so"])
+    lib = C.CDLL(os.path.join(CPP, "libhostlm_shim.so"))
+    lib.hlm_create.restype = C.c_void_p
+    lib.hlm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    for f in (lib.hlm_request, lib.hlm_supply, lib.hlm_result, lib.hlm_stats, lib.hlm_destroy):
+        f.argtypes = None
+    lib.hlm_request.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hlm_supply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hlm_result.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hlm_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hlm_destroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def run_host_lm(shim, ebo, orc, ev, prm, opts):
+    npx, npy = orc.grid(prm)
+    P = npx * npy
+    _, _, active, _ = orc.window_eval(ev, prm, np.zeros((P, 2)), want_jac=False)
+    act = active.astype(np.uint8)
+    h = shim.hlm_create(npx, npy, act.ctypes.data_as(C.c_void_p), prm.tv_weight, prm.tv_huber, C.byref(opts))
+    flows = np.zeros((P, 2))
+    rounds = 0
+    while True:
+        q = shim.hlm_request(h, flows.ctypes.data_as(C.c_void_p))
+        if q == 0:
+            break
+        r, J, _, _ = orc.window_eval(ev, prm, flows, want_jac=(q == 1))
+        Jp = J.ctypes.data_as(C.c_void_p) if q == 1 else None
+        shim.hlm_supply(h, r.ctypes.data_as(C.c_void_p), Jp)
+        rounds += 1
+    out = np.zeros((P, 2))
+    shim.hlm_result(h, out.ctypes.data_as(C.c_void_p))
+    st = np.zeros(4, dtype=np.int32)
+    costs = np.zeros(2)
+    shim.hlm_stats(h, st.ctypes.data_as(C.c_void_p), costs.ctypes.data_as(C.c_void_p))
+    shim.hlm_destroy(h)
+    return out, st, costs, rounds
+
+
+@pytest.mark.parametrize("loss,tv", [(1, 1e3), (1, 0.0), (0, 1e3)])
+def test_product_host_lm_matches_oracle_solver(shim, ebo, orc, synth, loss, tv):
+    n = 6000 if loss == 1 else 2500
+    ev, _ = synth.make_window(0, n_events=n)
+    iters = 50 if tv else 14
+    prm = orc.default_params(loss=loss, tv_weight=tv)
+    opts = ebo.default_solver(max_num_iterations=iters)
+    flows, st, costs, rounds = run_host_lm(shim, ebo, orc, ev, prm, opts)
+    fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(max_num_iterations=iters), want_image=False)
+    assert np.abs(flows - fo).max() <= 1e-9
+    assert st[0] == so.iterations and st[3] == so.termination
+    assert costs[0] == pytest.approx(so.initial_cost, rel=1e-14)
+    assert costs[1] == pytest.approx(so.final_cost, rel=1e-10)
+    assert rounds == st[1] + st[2]  # one batched evaluation per request
+
+
+def test_product_host_lm_degenerate_problems(shim, ebo, orc, synth):
+    """No active patch and no TV: nothing to solve; with TV only: stays at zero."""
+    ev, _ = synth.make_window(0, n_events=300)  # < 100 events in every patch
+    for tv in (0.0, 1e3):
+        prm = orc.default_params(loss=1, tv_weight=tv)
+        flows, st, costs, rounds = run_host_lm(shim, ebo, orc, ev, prm, ebo.default_solver())
+        assert np.all(flows == 0.0)
+        assert st[3] == 0
+        fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(), want_image=False)
+        assert np.all(fo == 0.0)
