@@ -336,7 +336,7 @@ class Context:
         if mode == COUNT_WARPED:
             aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.n_windows, self.P, 2)
             a = _vp(aux)
-        elif mode == COUNT_FIELD:
+        elif mode == COUNT_FIELD and aux is not None:
             aux = np.ascontiguousarray(aux, dtype=np.float32).reshape(
                 self.n_windows, self.params.image_h, self.params.image_w, 2)
             a = _vp(aux)
@@ -360,6 +360,22 @@ class Context:
         self.n_windows = 1
         self._custom = None
         return flows, img, s
+
+    def init_motion_field(self, timestamp, trajectories, use_average=True):
+        """FeatureDetector::initMotionField. trajectories: list of [(x, y, t_us), ...] per patch.
+        Returns (field float32 [H][W][2], fixed points [n][2])."""
+        offs = np.zeros(len(trajectories) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(t) for t in trajectories])
+        flat = [s for t in trajectories for s in t]
+        xy = np.ascontiguousarray([[s[0], s[1]] for s in flat], dtype=np.float64).reshape(-1, 2)
+        tt = np.ascontiguousarray([int(s[2]) for s in flat], dtype=np.int64)
+        field = np.zeros((self.params.image_h, self.params.image_w, 2), dtype=np.float32)
+        nfix = C.c_int32()
+        fixed = np.zeros((max(len(trajectories), 1), 2), dtype=np.int32)
+        self._check(lib().ebo_init_motion_field(
+            self._h, C.c_int64(int(timestamp)), int(bool(use_average)), len(trajectories), _vp(offs),
+            _vp(xy), _vp(tt), _vp(field), C.byref(nfix), _vp(fixed)))
+        return field, fixed[: nfix.value].copy()
 
     # -- tracked-feature patches (Patch::integrate*) --------------------------
     def patch_integrate(self, ev, offsets, rects):

@@ -66,6 +66,9 @@ struct ebo_ctx
 	size_t scratch_cap = 0;
 	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
 	size_t edge_scratch_cap = 0;
+	void* d_field = nullptr;         // motion field of ebo_init_motion_field (+ its staging)
+	size_t field_cap = 0;
+	bool field_valid = false;
 	void* d_raw = nullptr;           // raw 24-byte events staged for device bucketing
 	void* d_bucket = nullptr;        // bucketing scratch
 	size_t bucket_cap = 0;
@@ -1010,6 +1013,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_edge_scratch);
 	hipFree(c->d_raw);
 	hipFree(c->d_bucket);
+	hipFree(c->d_field);
 	if (c->ev0) hipEventDestroy(c->ev0);
 	if (c->ev1) hipEventDestroy(c->ev1);
 	if (c->own_stream && c->stream)
@@ -1711,7 +1715,10 @@ int ebo_count_image(ebo_ctx* c, int mode, const void* aux, double* image)
 	{
 		return EBO_ERR_ARG;
 	}
-	if (!image || mode < 0 || mode > 2 || (mode != EBO_COUNT_INTEGRATED && !aux))
+	// EBO_COUNT_FIELD with aux == NULL: the field left on the device by
+	// ebo_init_motion_field (one window only: the field belongs to the context)
+	const bool residentField = mode == EBO_COUNT_FIELD && !aux && c->field_valid && c->n_windows == 1;
+	if (!image || mode < 0 || mode > 2 || (mode != EBO_COUNT_INTEGRATED && !aux && !residentField))
 	{
 		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image");
 	}
@@ -1728,6 +1735,10 @@ int ebo_count_image(ebo_ctx* c, int mode, const void* aux, double* image)
 		const size_t bytes = static_cast<size_t>(c->n_windows) * c->P * 2 * sizeof(double);
 		rc = c->hip(hipMemcpyAsync(c->d_flows, aux, bytes, hipMemcpyHostToDevice, c->stream), "H2D flows");
 		d_aux = c->d_flows;
+	}
+	else if (residentField)
+	{
+		d_aux = c->d_field;
 	}
 	else if (mode == EBO_COUNT_FIELD)
 	{
@@ -1966,6 +1977,110 @@ int ebo_patch_integrate_mc(ebo_ctx* c, const ebo_event* ev, const size_t* offset
 	}
 	return patch_integrate_common(c, ev, offsets, n_patches, rects, traj, mid_time, nabla_offsets,
 								  nabla, nullptr, nullptr, updated);
+}
+
+// FeatureDetector::initMotionField (feature_detector.cpp:53-142).
+int ebo_init_motion_field(ebo_ctx* c, int64_t timestamp, int use_average, int n_patches,
+						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
+						  float* field_out, int32_t* n_fixed, int32_t* fixed_xy)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (n_patches < 0 || (n_patches > 0 && (!traj_offsets || !traj_xy || !traj_t)))
+	{
+		return c->fail(EBO_ERR_ARG, "null trajectory arrays");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const int w = c->prm.image_w, h = c->prm.image_h;
+	const size_t npx = static_cast<size_t>(w) * h;
+	const size_t nSamples = n_patches > 0 ? traj_offsets[n_patches] : 0;
+	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+	const size_t bField = al(npx * 2 * sizeof(float));
+	const size_t bOff = al((static_cast<size_t>(n_patches) + 1) * 8), bXY = al(nSamples * 16), bT = al(nSamples * 8);
+	const size_t bFix = al(static_cast<size_t>(std::max(n_patches, 1)) * 8);
+	const size_t need = bField + bOff + bXY + bT + bFix + 512;
+	if (need > c->field_cap)
+	{
+		if (c->d_field)
+		{
+			hipFree(c->d_field);
+			c->d_field = nullptr;
+			c->field_cap = 0;
+		}
+		int rc = c->hip(hipMalloc(&c->d_field, need), "hipMalloc motion field");
+		if (rc)
+		{
+			return rc;
+		}
+		c->field_cap = need;
+	}
+	char* base = static_cast<char*>(c->d_field);
+	FieldLaunch L;
+	L.w = w;
+	L.h = h;
+	L.scale = c->prm.scale;
+	L.use_average = use_average ? 1 : 0;
+	L.n_patches = n_patches;
+	L.d_field = reinterpret_cast<float*>(base);
+	L.d_off = reinterpret_cast<unsigned long long*>(base + bField);
+	L.d_xy = reinterpret_cast<double*>(base + bField + bOff);
+	L.d_t = reinterpret_cast<long long*>(base + bField + bOff + bXY);
+	L.d_fixed = reinterpret_cast<int*>(base + bField + bOff + bXY + bT);
+	L.d_avg = reinterpret_cast<double*>(base + bField + bOff + bXY + bT + bFix);
+	L.d_nfixed = reinterpret_cast<int*>(base + bField + bOff + bXY + bT + bFix + 256);
+	L.timestamp = timestamp;
+	std::vector<unsigned long long> off64(static_cast<size_t>(n_patches) + 1, 0ull);
+	for (int k = 0; k <= n_patches && n_patches > 0; ++k)
+	{
+		off64[k] = traj_offsets[k];
+	}
+	hipError_t e = hipMemcpyAsync(const_cast<unsigned long long*>(L.d_off), off64.data(), off64.size() * 8,
+								  hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && nSamples)
+	{
+		e = hipMemcpyAsync(const_cast<double*>(L.d_xy), traj_xy, nSamples * 16, hipMemcpyHostToDevice, c->stream);
+	}
+	if (e == hipSuccess && nSamples)
+	{
+		e = hipMemcpyAsync(const_cast<long long*>(L.d_t), traj_t, nSamples * 8, hipMemcpyHostToDevice, c->stream);
+	}
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D trajectories");
+	}
+	if (launch_init_field(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "motion field launch");
+	}
+	int nf = 0;
+	if (field_out)
+	{
+		e = hipMemcpyAsync(field_out, L.d_field, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess)
+	{
+		e = hipMemcpyAsync(&nf, L.d_nfixed, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess)
+	{
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e == hipSuccess && fixed_xy && nf > 0)
+	{
+		e = hipMemcpy(fixed_xy, L.d_fixed, static_cast<size_t>(nf) * 8, hipMemcpyDeviceToHost);
+	}
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "D2H motion field");
+	}
+	if (n_fixed)
+	{
+		*n_fixed = nf;
+	}
+	c->field_valid = true;
+	return EBO_OK;
 }
 
 // DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one

@@ -183,6 +183,24 @@ struct BucketLaunch
 };
 int launch_bucket(const BucketLaunch& L, void* stream);
 
+// FeatureDetector::initMotionField (ebo_field.inc).
+struct FieldLaunch
+{
+	int w, h;
+	double scale;
+	int use_average;
+	int n_patches;
+	const unsigned long long* d_off; // [n_patches + 1]
+	const double* d_xy;              // [samples][2]
+	const long long* d_t;            // [samples]
+	long long timestamp;
+	float* d_field;                  // out [h][w][2]
+	int* d_fixed;                    // out [n_patches][2]
+	double* d_avg;                   // scratch [3]
+	int* d_nfixed;                   // out
+};
+int launch_init_field(const FieldLaunch& L, void* stream);
+
 struct PatchIntLaunch
 {
 	const uint64_t* d_events;  // packed, dt = mid_time - t

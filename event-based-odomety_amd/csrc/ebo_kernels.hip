@@ -1357,6 +1357,7 @@ __global__ void k_patch_integrate(const uint64_t* __restrict__ events,
 
 #include "ebo_edge.inc"
 #include "ebo_bucket.inc"
+#include "ebo_field.inc"
 
 int check_launch()
 {
@@ -1430,6 +1431,25 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 						   L.d_units, L.n_units, L.d_flows, L.tiles, L.flow_sets, L.channels,
 						   L.fd_step, L.d_partials, L.d_out, L.c);
 	}
+	return check_launch();
+}
+
+int launch_init_field(const FieldLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const size_t npx = static_cast<size_t>(L.w) * L.h;
+	if (hipMemsetAsync(L.d_field, 0, npx * 2 * sizeof(float), s) != hipSuccess)
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_field_fixed, dim3(1), dim3(64), 0, s, L.w, L.h, L.scale, L.n_patches, L.d_off,
+					   L.d_xy, L.d_t, L.timestamp, L.d_field, L.d_fixed, L.d_avg, L.d_nfixed);
+	if (check_launch())
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_field_fill, dim3(static_cast<unsigned>((npx + 255) / 256)), dim3(256), 0, s, L.w,
+					   L.h, L.use_average, L.d_field, L.d_fixed, L.d_avg, L.d_nfixed);
 	return check_launch();
 }
 

@@ -206,6 +206,19 @@ int ebo_count_image(ebo_ctx* ctx, int mode, const void* aux, double* image);
 /* Same with aux and image on the device; asynchronous. */
 int ebo_count_image_device(ebo_ctx* ctx, int mode, const void* d_aux, double* d_image);
 
+/* tracker::FeatureDetector::initMotionField (feature_detector.cpp:53-142): per-pixel motion
+ * field from the trajectories of the tracked feature patches.  Patch k has trajectory samples
+ * traj_xy[traj_offsets[k]..traj_offsets[k+1])[2], traj_t[...] (us, ascending).  The velocity of
+ * the segment at `timestamp` (std::lower_bound) is stored at the rounded trajectory point; the
+ * other pixels get the average (use_average, DetectorParams::useAverageFlow) or the nearest
+ * fixed point's value.  field_out: host float32 [image_h][image_w][2] (may be NULL);
+ * fixed_xy: host [n_patches][2] (may be NULL).  The field also stays on the device:
+ * ebo_count_image(ctx, EBO_COUNT_FIELD, NULL, image) then is R4 (compensateEvents) end to end.
+ * interpolateMotionField's per-pixel TV smoothing (:144-241) is not built. */
+int ebo_init_motion_field(ebo_ctx* ctx, int64_t timestamp, int use_average, int n_patches,
+						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
+						  float* field_out, int32_t* n_fixed, int32_t* fixed_xy);
+
 /* R2 in one call: set window, solve, final warped count image.
  * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */
 int ebo_compensate_events_contrast(ebo_ctx* ctx, const ebo_event* ev, size_t n,

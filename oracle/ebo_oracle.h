@@ -173,6 +173,13 @@ int orc_compensate_events_field(const orc_event* ev, size_t n, int w, int h,
 								double scale, const float* field,
 								double* image);
 
+/* FeatureDetector::initMotionField (feature_detector.cpp:53-142): velocities at the tracked
+ * patches' positions from their trajectories (lower_bound by time), the rest filled with the
+ * average or the nearest fixed point.  field float32 [h][w][2]; fixed_xy [n_patches][2]. */
+int orc_init_motion_field(int w, int h, double scale, int use_average, int n_patches,
+						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
+						  int64_t timestamp, float* field, int32_t* n_fixed, int32_t* fixed_xy);
+
 /* Patch::integrateEvents (patch.cpp:65-85). ev in deque order (front = newest).
  * nabla [int(rh)][int(rw)]. */
 int orc_patch_integrate(const orc_event* ev, size_t n, double rx, double ry,

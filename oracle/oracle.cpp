@@ -1413,6 +1413,103 @@ int orc_compensate_events_field(const orc_event* ev, size_t n, int w, int h,
 	return 0;
 }
 
+// FeatureDetector::initMotionField (feature_detector.cpp:53-142).  The field is the
+// at<cv::Vec2f> view the reference uses, i.e. float32 [h][w][2].  Patch k
+// contributes its trajectory samples traj[off[k]..off[k+1]) = (x, y, t_us).
+// A trajectory point that rounds outside the image is written out of bounds by the
+// reference (undefined); such a patch is skipped here.
+int orc_init_motion_field(int w, int h, double scale, int use_average, int n_patches,
+						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
+						  int64_t timestamp, float* field, int32_t* n_fixed, int32_t* fixed_xy)
+{
+	if (!field || w <= 0 || h <= 0 || (n_patches > 0 && (!traj_offsets || !traj_xy || !traj_t)))
+	{
+		return -1;
+	}
+	std::fill(field, field + static_cast<size_t>(w) * h * 2, 0.0f);
+	std::vector<int> fx, fy;
+	double avgX = 0.0, avgY = 0.0, count = 0.0;
+	if (timestamp > 0 && n_patches > 0)  // :60
+	{
+		for (int k = 0; k < n_patches; ++k)
+		{
+			const size_t a = traj_offsets[k], b = traj_offsets[k + 1];
+			// std::lower_bound by lhs.timestamp < target (:66-72)
+			size_t low = a;
+			while (low < b && traj_t[low] < timestamp)
+			{
+				++low;
+			}
+			if (low != b && low + 1 != b)  // :73-74
+			{
+				const int px = static_cast<int>(std::round(traj_xy[2 * low]));
+				const int py = static_cast<int>(std::round(traj_xy[2 * low + 1]));
+				if (px < 0 || px >= w || py < 0 || py >= h)
+				{
+					continue;
+				}
+				float* f = field + 2 * (static_cast<size_t>(py) * w + px);
+				const double dt = static_cast<double>(traj_t[low + 1] - traj_t[low]);
+				f[0] = static_cast<float>((1 / scale) * (traj_xy[2 * (low + 1)] - traj_xy[2 * low]) / dt);
+				f[1] = static_cast<float>((1 / scale) * (traj_xy[2 * (low + 1) + 1] - traj_xy[2 * low + 1]) / dt);
+				fx.push_back(px);
+				fy.push_back(py);
+				avgX += f[0];
+				avgY += f[1];
+				count += 1.0;
+			}
+		}
+		if (!fx.empty())  // :100-140
+		{
+			for (int y = 0; y < h; ++y)
+			{
+				for (int x = 0; x < w; ++x)
+				{
+					float* f = field + 2 * (static_cast<size_t>(y) * w + x);
+					if (f[0] == 0 && f[1] == 0)
+					{
+						if (use_average)
+						{
+							f[0] = static_cast<float>(avgX / count);
+							f[1] = static_cast<float>(avgY / count);
+						}
+						else
+						{
+							int bestId = 0;
+							double bestDist = 1e16;
+							for (int id = 0; id < static_cast<int>(fx.size()); ++id)
+							{
+								const double dist = (x - fx[id]) * (x - fx[id]) + (y - fy[id]) * (y - fy[id]);
+								if (dist < bestDist)
+								{
+									bestDist = dist;
+									bestId = id;
+								}
+							}
+							const float* g = field + 2 * (static_cast<size_t>(fy[bestId]) * w + fx[bestId]);
+							f[0] = g[0];
+							f[1] = g[1];
+						}
+					}
+				}
+			}
+		}
+	}
+	if (n_fixed)
+	{
+		*n_fixed = static_cast<int32_t>(fx.size());
+	}
+	if (fixed_xy)
+	{
+		for (size_t i = 0; i < fx.size(); ++i)
+		{
+			fixed_xy[2 * i] = fx[i];
+			fixed_xy[2 * i + 1] = fy[i];
+		}
+	}
+	return 0;
+}
+
 // patch.cpp:65-85.  cv::Rect2d::contains on the int point; frameToPatchCoords
 // (patch.cpp:184-189) converts (int - double) back to int by truncation.
 int orc_patch_integrate(const orc_event* ev, size_t n, double rx, double ry,

@@ -296,3 +296,22 @@ def parse_events_txt(path, cap=1 << 20):
 
 def mid_timestamp(front, back):
     return lib().orc_mid_timestamp(int(front), int(back))
+
+
+def init_motion_field(w, h, timestamp, trajectories, use_average=True, scale=1e-3):
+    """FeatureDetector::initMotionField. trajectories: list of [(x, y, t_us), ...] per patch."""
+    offs = np.zeros(len(trajectories) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(t) for t in trajectories])
+    flat = [s for t in trajectories for s in t]
+    xy = np.ascontiguousarray([[s[0], s[1]] for s in flat], dtype=np.float64).reshape(-1, 2)
+    tt = np.ascontiguousarray([int(s[2]) for s in flat], dtype=np.int64)
+    field = np.zeros((h, w, 2), dtype=np.float32)
+    nfix = C.c_int32()
+    fixed = np.zeros((max(len(trajectories), 1), 2), dtype=np.int32)
+    rc = lib().orc_init_motion_field(
+        int(w), int(h), C.c_double(scale), int(bool(use_average)), len(trajectories),
+        offs.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p),
+        C.c_int64(int(timestamp)), field.ctypes.data_as(C.c_void_p), C.byref(nfix),
+        fixed.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return field, fixed[: nfix.value].copy()
