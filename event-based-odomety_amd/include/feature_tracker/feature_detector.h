@@ -197,6 +197,31 @@ class FeatureDetector
 		check(ebo_count_image(ctx_, EBO_COUNT_FIELD, motionField_.data(), compensatedEventImage_.ptr()));
 	}
 
+	// feature_detector.cpp:53-142.  The reference reads the trajectories of its tracked
+	// Patches (Patch::getTrajectory(), frame-based tracker, outside this path); hand them in with
+	// setPatchTrajectories().  useAverageFlow selects average vs nearest fill.
+	using Trajectory = std::vector<common::Sample<common::Point2d>>;
+	void setPatchTrajectories(const std::vector<Trajectory>& trajectories) { trajectories_ = trajectories; }
+	void initMotionField(const common::timestamp_t timestamp)
+	{
+		std::vector<size_t> off(1, 0);
+		std::vector<double> xy;
+		std::vector<int64_t> tt;
+		for (const auto& tr : trajectories_)
+		{
+			for (const auto& s : tr)
+			{
+				xy.push_back(s.value.x);
+				xy.push_back(s.value.y);
+				tt.push_back(s.timestamp.count());
+			}
+			off.push_back(tt.size());
+		}
+		check(ebo_init_motion_field(ctx_, timestamp.count(), params_.useAverageFlow ? 1 : 0,
+									static_cast<int>(trajectories_.size()), off.data(), xy.data(), tt.data(),
+									motionField_.data(), nullptr, nullptr));
+	}
+
 	// float32 [height][width][2], the at<cv::Vec2f> view of the reference's motionField_
 	void setMotionField(const std::vector<float>& field)
 	{
@@ -236,6 +261,7 @@ class FeatureDetector
 	Mat64 compensatedEventImage_;
 	Mat64 integratedEventImage_;
 	std::vector<float> motionField_;
+	std::vector<Trajectory> trajectories_;
 	std::vector<double> patchFlows_;
 	std::list<common::EventSample> lastEvents_;
 	common::timestamp_t lastCompensation;
