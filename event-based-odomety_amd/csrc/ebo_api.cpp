@@ -331,7 +331,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,1024]");
 	}
-	const size_t headerBytes = 168 * sizeof(double);
+	const size_t headerBytes = (168 + 512) * sizeof(double);  // kEdgeHeader
 	const size_t canvasPx = static_cast<size_t>(9) * c->max_rw * c->max_rh;
 	const size_t bytesPerPx = 3 * sizeof(double) + sizeof(int32_t);
 	size_t ldsBytes = std::min<size_t>(env_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
@@ -386,7 +386,14 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 			L.ec.w[(i + 3) * 7 + (j + 3)] = normCoef * std::exp(-0.5 / sigmaSq * (x * x + y * y));
 		}
 	}
+	for (int k = -3; k <= 3; ++k)
+	{
+		L.ec.g[k + 3] = std::exp(-0.5 / sigmaSq * static_cast<double>(k * k));
+	}
+	L.ec.norm_st = normCoef;
 	L.ec.mean_threshold = 0.0001;
+	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
+	L.ec.reserved = 0;
 	if (launch_eval_edge(L, c->stream))
 	{
 		return c->hip(hipGetLastError(), "edge eval launch");

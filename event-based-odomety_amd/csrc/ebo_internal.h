@@ -104,7 +104,11 @@ int launch_dump_image(const EvalLaunch& L, int unit, double* d_image, void* stre
 struct EdgeConsts
 {
 	double w[49];          // tensor weights [i+3][j+3] = gaussian(0,0,j,i,sigmaST) (:193-202)
+	double g[7];           // 1-D factors exp(hs_st k^2), k = -3..3:  w(i,j) = norm_st g[i] g[j]
+	double norm_st;        // 1 / (2 pi sigmaST^2)
 	double mean_threshold; // 1e-4 (:159)
+	int ablate;            // timing-only ablation mask (EBO_EDGE_ABLATE): 1 eigen, 2 NMS, 4 reverse, 8 gather, 16 scatter
+	int reserved;
 };
 
 struct EdgeLaunch

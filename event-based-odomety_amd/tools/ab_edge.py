@@ -16,7 +16,7 @@ d_out = torch.zeros((windows * ctx.P, 3), dtype=torch.float64, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ref = None
 for st in sys.argv[3:] or [""]:
-    for k in ("EBO_EDGE_BLOCK", "EBO_EDGE_LDS_KB"):
+    for k in ("EBO_EDGE_BLOCK", "EBO_EDGE_LDS_KB", "EBO_EDGE_ABLATE"):
         os.environ.pop(k, None)
     for kv in filter(None, st.split(",")):
         k, v = kv.split("="); os.environ[k] = v
