@@ -179,6 +179,15 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the other ranks receive its bytes)."""
+    buf = (C.c_char * 128)()
+    rc = lib().ebo_comm_unique_id(C.byref(buf))
+    if rc:
+        raise EboError(rc, lib().ebo_last_error(None).decode())
+    return bytes(buf)
+
+
 def read_events_txt(path, cap=1 << 22):
     """DAVIS240C events.txt -> structured event array (host-side parser of the library)."""
     out = np.zeros(cap, dtype=EVENT_DTYPE)
@@ -413,6 +422,18 @@ class Context:
         imgs = [nabla[int(noff[i]):int(noff[i]) + sizes[i]].reshape(int(rects[i][3]), int(rects[i][2]))
                 for i in range(n)]
         return imgs, upd
+
+    # -- RCCL exchange (no framework) -----------------------------------------
+    def comm_init(self, comm_id, rank, nranks):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(comm_id))
+        self._check(lib().ebo_comm_init(self._h, C.byref(buf), int(rank), int(nranks)))
+
+    def allgather_device(self, d_send, d_recv, count_per_rank):
+        self._check(lib().ebo_allgather_device(
+            self._h, C.c_void_p(int(d_send)), C.c_void_p(int(d_recv)), C.c_size_t(int(count_per_rank))))
+
+    def comm_destroy(self):
+        self._check(lib().ebo_comm_destroy(self._h))
 
     # -- timing --------------------------------------------------------------
     def timer_begin(self):

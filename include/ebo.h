@@ -43,6 +43,7 @@ extern "C" {
 #define EBO_ERR_UNSUPPORTED (-5) /* parameter combination not built            */
 #define EBO_ERR_NO_DEVICE (-6)   /* no HIP device / not gfx950                 */
 #define EBO_ERR_SOLVER (-7)      /* solver terminated with FAILURE             */
+#define EBO_ERR_COMM (-8)        /* RCCL could not be loaded or a collective failed */
 
 #define EBO_LOSS_EDGE 0     /* contrastFunctor::calculateEdgeLoss (reference default, :152-277) */
 #define EBO_LOSS_VARIANCE 1 /* contrastFunctor::calculateVarianceLoss (:101-150, north-star objective) */
@@ -246,6 +247,21 @@ int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
 
 /* Contiguous shard [begin,end) of n_units for rank of world (multi-GPU, §8e). */
 int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end);
+
+/* Multi-GPU exchange (one process per GPU, RCCL over xGMI) for callers without a framework:
+ * rank 0 makes an id (ebo_comm_unique_id) and hands its 128 bytes to the other ranks by any
+ * means; every rank calls ebo_comm_init on its context; ebo_allgather_device gathers
+ * count_per_rank doubles from every rank into d_recv [nranks][count_per_rank] on every rank,
+ * asynchronously on the context's stream -- the single all-gather of the solved flows (or of
+ * the (r, J0, J1) triples) of SURVEY 8(e).  librccl.so is loaded on first use only. */
+typedef struct ebo_comm_id
+{
+	char internal[128];
+} ebo_comm_id;
+int ebo_comm_unique_id(ebo_comm_id* id);
+int ebo_comm_init(ebo_ctx* ctx, const ebo_comm_id* id, int rank, int nranks);
+int ebo_allgather_device(ebo_ctx* ctx, const double* d_send, double* d_recv, size_t count_per_rank);
+int ebo_comm_destroy(ebo_ctx* ctx);
 
 /* Device-side timing of everything enqueued between begin and end on the
  * context's stream (hipEvent based). */
