@@ -386,6 +386,17 @@ class Context:
             _vp(xy), _vp(tt), _vp(field), C.byref(nfix), _vp(fixed)))
         return field, fixed[: nfix.value].copy()
 
+    def interpolate_motion_field(self, use_l1=False, opts=None):
+        """FeatureDetector::interpolateMotionField on the field of the last init_motion_field.
+        Returns (field float32 [H][W][2], Summary, total CG iterations)."""
+        field = np.zeros((self.params.image_h, self.params.image_w, 2), dtype=np.float32)
+        s = Summary()
+        cg = C.c_int32()
+        self._check(lib().ebo_interpolate_motion_field(
+            self._h, int(bool(use_l1)), C.byref(opts) if opts is not None else None, _vp(field),
+            C.byref(s), C.byref(cg)))
+        return field, s, cg.value
+
     # -- tracked-feature patches (Patch::integrate*) --------------------------
     def patch_integrate(self, ev, offsets, rects):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)

@@ -15,6 +15,7 @@
 
 #include "../../include/ebo.h"
 #include "ebo_internal.h"
+#include "field_tv.h"
 #include "host_lm.h"
 
 using namespace ebo;
@@ -70,6 +71,10 @@ struct ebo_ctx
 	void* d_field = nullptr;         // motion field of ebo_init_motion_field (+ its staging)
 	size_t field_cap = 0;
 	bool field_valid = false;
+	const int* d_field_fixed = nullptr;  // fixed points of that field, [field_nfixed][2]
+	int field_nfixed = 0;
+	void* d_tvf = nullptr;           // workspace of ebo_interpolate_motion_field
+	size_t tvf_cap = 0;
 	void* comm = nullptr;            // ncclComm_t of ebo_comm_init
 	int comm_rank = 0, comm_size = 1;
 	void* d_raw = nullptr;           // raw 24-byte events staged for device bucketing
@@ -1027,6 +1032,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_raw);
 	hipFree(c->d_bucket);
 	hipFree(c->d_field);
+	hipFree(c->d_tvf);
 	if (c->ev0) hipEventDestroy(c->ev0);
 	if (c->ev1) hipEventDestroy(c->ev1);
 	if (c->own_stream && c->stream)
@@ -2093,7 +2099,111 @@ int ebo_init_motion_field(ebo_ctx* c, int64_t timestamp, int use_average, int n_
 		*n_fixed = nf;
 	}
 	c->field_valid = true;
+	c->d_field_fixed = L.d_fixed;
+	c->field_nfixed = nf;
 	return EBO_OK;
+}
+
+int ebo_interpolate_motion_field(ebo_ctx* c, int use_l1, const ebo_solver_opts* opts, float* field_out,
+								 ebo_summary* summary, int32_t* cg_iterations)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!c->field_valid)
+	{
+		return c->fail(EBO_ERR_STATE, "ebo_interpolate_motion_field needs ebo_init_motion_field first");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const int w = c->prm.image_w, h = c->prm.image_h;
+	if (w < 2 || h < 2)
+	{
+		return c->fail(EBO_ERR_ARG, "image too small for the TV problem");
+	}
+	// a fixed point at pixel (w-1, h-1) is no parameter block of the reference's problem
+	// (feature_detector.cpp:170-204): Ceres aborts in IsParameterBlockConstant (:208)
+	std::vector<int32_t> fixed(static_cast<size_t>(c->field_nfixed) * 2);
+	if (c->field_nfixed > 0)
+	{
+		int rc = c->hip(hipMemcpyAsync(fixed.data(), c->d_field_fixed, fixed.size() * sizeof(int32_t),
+									   hipMemcpyDeviceToHost, c->stream), "D2H fixed points");
+		if (rc == EBO_OK)
+		{
+			rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+		}
+		if (rc)
+		{
+			return rc;
+		}
+		for (int i = 0; i < c->field_nfixed; ++i)
+		{
+			if (fixed[2 * i] == w - 1 && fixed[2 * i + 1] == h - 1)
+			{
+				return c->fail(EBO_ERR_RANGE, "fixed point at the last pixel: not a parameter of the TV problem");
+			}
+		}
+	}
+	const size_t need = tvf_workspace_bytes(w, h);
+	if (need > c->tvf_cap)
+	{
+		if (c->d_tvf)
+		{
+			hipFree(c->d_tvf);
+			c->d_tvf = nullptr;
+			c->tvf_cap = 0;
+		}
+		int rc = c->hip(hipMalloc(&c->d_tvf, need), "hipMalloc TV workspace");
+		if (rc)
+		{
+			return rc;
+		}
+		c->tvf_cap = need;
+	}
+	ebo_solver_opts o;
+	if (opts)
+	{
+		o = *opts;
+	}
+	else
+	{
+		// ceres::Solver::Options defaults with feature_detector.cpp:216-222 applied
+		ebo_default_solver(&o);
+		o.use_nonmonotonic = 0;
+		o.function_tolerance = 1e-6;
+		o.gradient_tolerance = 1e-10;
+		o.parameter_tolerance = 1e-8;
+	}
+	FieldTvStats st;
+	int rc = field_tv_solve(w, h, static_cast<float*>(c->d_field), c->d_field_fixed, c->field_nfixed,
+							use_l1 != 0, o, c->d_tvf, c->stream, &st, &c->err);
+	if (rc)
+	{
+		return rc;
+	}
+	if (summary)
+	{
+		summary->iterations = st.iterations;
+		summary->num_evals_cost = st.evals_cost;
+		summary->num_evals_jac = st.evals_jac;
+		summary->termination = st.termination;
+		summary->initial_cost = st.initial_cost;
+		summary->final_cost = st.final_cost;
+	}
+	if (cg_iterations)
+	{
+		*cg_iterations = st.cg_iterations;
+	}
+	if (field_out)
+	{
+		rc = c->hip(hipMemcpy(field_out, c->d_field, static_cast<size_t>(w) * h * 2 * sizeof(float),
+							  hipMemcpyDeviceToHost), "D2H motion field");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	return st.termination == 2 ? c->fail(EBO_ERR_SOLVER, "field TV solve failed") : EBO_OK;
 }
 
 // DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one

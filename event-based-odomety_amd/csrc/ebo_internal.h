@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 namespace ebo
 {
 // One event in HBM: 8 bytes (the algorithmic bytes per
@@ -204,6 +206,42 @@ struct FieldLaunch
 	int* d_nfixed;                   // out
 };
 int launch_init_field(const FieldLaunch& L, void* stream);
+
+// interpolateMotionField's per-pixel TV problem (ebo_fieldtv.inc / field_tv.cpp).
+// n = w * h pixels; "2" vectors hold both flow components of a pixel side by side.
+struct TvfArgs
+{
+	int w, h, n;
+	unsigned char* mask;  // 0 free, 1 fixed point, 2 not in the problem (pixel (w-1, h-1))
+	double* wh;           // weight of edge p-(p+1), 0 where the block does not exist
+	double* wv;           // weight of edge p-(p+w)
+	double* deg;          // sum of the incident weights = diag(J'J)
+	double* s2;           // Jacobi scaling squared, from iteration 0
+	double* diag;         // deg + damping (the CG preconditioner)
+	double2* x;           // current point
+	double2* xc;          // candidate
+	double2* g;           // gradient
+	double2* y;           // LM step (unscaled)
+	double2* r;
+	double2* z;
+	double2* p0;
+	double2* p1;
+	double2* q;
+	double* partials;     // [4 * 1024] per-workgroup sums of the last kernel
+	double* partials_rz;  // [4 * 1024] same, for r'z / r'r (read while `partials` is rewritten)
+	double* scal;         // [32] reduction results, see ebo_fieldtv.inc
+	double huber_a;       // 0: no loss (useL1 false); 1e-5: HuberLoss(1e-5)
+	double lm_lo, lm_hi;  // min/max_lm_diagonal
+};
+size_t tvf_workspace_bytes(int w, int h);
+void tvf_carve(TvfArgs& A, int w, int h, void* base, double2** xbest);
+int launch_tvf_prepare(const TvfArgs& A, const float* d_field, const int* d_fixed, int n_fixed, void* stream);
+int launch_tvf_linearize(const TvfArgs& A, const double2* X, int first, int cost_only, void* stream);
+int launch_tvf_cg_init(const TvfArgs& A, double radius, void* stream);
+// CG iterations first_iter .. first_iter + iters - 1 (iteration k reads direction buffer k & 1).
+int launch_tvf_cg_iters(const TvfArgs& A, int first_iter, int iters, void* stream);
+int launch_tvf_model(const TvfArgs& A, void* stream);
+int launch_tvf_store(const TvfArgs& A, const double2* X, float* d_field, void* stream);
 
 struct PatchIntLaunch
 {

@@ -19,6 +19,8 @@
 // the CPU path (one rounding per operation) because it is truncated to a bin.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "ebo_internal.h"
 
 namespace ebo
@@ -1358,6 +1360,7 @@ __global__ void k_patch_integrate(const uint64_t* __restrict__ events,
 #include "ebo_edge.inc"
 #include "ebo_bucket.inc"
 #include "ebo_field.inc"
+#include "ebo_fieldtv.inc"
 
 int check_launch()
 {
@@ -1450,6 +1453,128 @@ int launch_init_field(const FieldLaunch& L, void* stream)
 	}
 	hipLaunchKernelGGL(k_field_fill, dim3(static_cast<unsigned>((npx + 255) / 256)), dim3(256), 0, s, L.w,
 					   L.h, L.use_average, L.d_field, L.d_fixed, L.d_avg, L.d_nfixed);
+	return check_launch();
+}
+
+size_t tvf_workspace_bytes(int w, int h)
+{
+	const size_t n = static_cast<size_t>(w) * h;
+	const size_t nAl = (n + 255) & ~static_cast<size_t>(255);
+	return nAl /*mask*/ + 5 * nAl * 8 + 10 * nAl * 16 + 2 * (4 * 1024 * 8) + 256 /*scal*/;
+}
+
+void tvf_carve(TvfArgs& A, int w, int h, void* base, double2** xbest)
+{
+	const size_t n = static_cast<size_t>(w) * h;
+	const size_t nAl = (n + 255) & ~static_cast<size_t>(255);
+	char* b = static_cast<char*>(base);
+	auto take = [&](size_t bytes) {
+		char* r = b;
+		b += (bytes + 255) & ~static_cast<size_t>(255);
+		return r;
+	};
+	A.w = w;
+	A.h = h;
+	A.n = static_cast<int>(n);
+	double2** v2[] = {&A.x, &A.xc, xbest, &A.g, &A.y, &A.r, &A.z, &A.p0, &A.p1, &A.q};
+	for (double2** v : v2)
+	{
+		*v = reinterpret_cast<double2*>(take(nAl * 16));
+	}
+	double** v1[] = {&A.wh, &A.wv, &A.deg, &A.s2, &A.diag};
+	for (double** v : v1)
+	{
+		*v = reinterpret_cast<double*>(take(nAl * 8));
+	}
+	A.partials = reinterpret_cast<double*>(take(4 * 1024 * 8));
+	A.partials_rz = reinterpret_cast<double*>(take(4 * 1024 * 8));
+	A.scal = reinterpret_cast<double*>(take(256));
+	A.mask = reinterpret_cast<unsigned char*>(take(nAl));
+}
+
+namespace
+{
+// Workgroups of the chunk-walking kernels: a multiple of 8 (one band per XCD), <= 1024.
+unsigned tvf_grid(int n)
+{
+	const int chunks = (n + 255) / 256;
+	const int perBand = (chunks + 7) / 8;
+	return 8u * static_cast<unsigned>(std::min(perBand, 128));
+}
+}  // namespace
+
+int launch_tvf_prepare(const TvfArgs& A, const float* d_field, const int* d_fixed, int n_fixed, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (hipMemsetAsync(A.scal, 0, 256, s) != hipSuccess)
+	{
+		return -2;
+	}
+	const unsigned G = tvf_grid(A.n);
+	hipLaunchKernelGGL(k_tvf_prepare, dim3(G), dim3(256), 0, s, A, reinterpret_cast<const float2*>(d_field));
+	hipLaunchKernelGGL((k_tvf_reduce<1, 0>), dim3(1), dim3(256), 0, s, A.partials, static_cast<int>(G),
+					   A.scal + kTvfNorm, 1);
+	if (n_fixed > 0)
+	{
+		hipLaunchKernelGGL(k_tvf_mark_fixed, dim3((n_fixed + 255) / 256), dim3(256), 0, s, A, d_fixed, n_fixed);
+	}
+	return check_launch();
+}
+
+int launch_tvf_linearize(const TvfArgs& A, const double2* X, int first, int cost_only, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const unsigned G = tvf_grid(A.n);
+	hipLaunchKernelGGL(k_tvf_linearize, dim3(G), dim3(256), 0, s, A, X, first, cost_only);
+	// cost only: the |x|^2 and max |g| slots of the current point stay as they are
+	if (cost_only)
+	{
+		hipLaunchKernelGGL((k_tvf_reduce<3, 1>), dim3(1), dim3(256), 0, s, A.partials, static_cast<int>(G),
+						   A.scal + 20, 0);
+	}
+	else
+	{
+		hipLaunchKernelGGL((k_tvf_reduce<3, 1>), dim3(1), dim3(256), 0, s, A.partials, static_cast<int>(G),
+						   A.scal + kTvfCost, 0);
+	}
+	return check_launch();
+}
+
+int launch_tvf_cg_init(const TvfArgs& A, double radius, void* stream)
+{
+	hipLaunchKernelGGL(k_tvf_cg_init, dim3(tvf_grid(A.n)), dim3(256), 0, static_cast<hipStream_t>(stream), A, radius);
+	return check_launch();
+}
+
+int launch_tvf_cg_iters(const TvfArgs& A, int first_iter, int iters, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const unsigned G = tvf_grid(A.n);
+	for (int k = first_iter; k < first_iter + iters; ++k)
+	{
+		const double2* pOld = (k & 1) ? A.p1 : A.p0;
+		double2* pNew = (k & 1) ? A.p0 : A.p1;
+		hipLaunchKernelGGL(k_tvf_cg_apply, dim3(G), dim3(256), 0, s, A, pOld, pNew, k);
+		hipLaunchKernelGGL(k_tvf_cg_update, dim3(G), dim3(256), 0, s, A, pNew, k);
+	}
+	return check_launch();
+}
+
+int launch_tvf_model(const TvfArgs& A, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const unsigned G = tvf_grid(A.n);
+	hipLaunchKernelGGL(k_tvf_model, dim3(G), dim3(256), 0, s, A);
+	hipLaunchKernelGGL((k_tvf_reduce<3, 0>), dim3(1), dim3(256), 0, s, A.partials, static_cast<int>(G),
+					   A.scal + kTvfYg, 0);
+	return check_launch();
+}
+
+int launch_tvf_store(const TvfArgs& A, const double2* X, float* d_field, void* stream)
+{
+	const unsigned blocks = static_cast<unsigned>((A.n + 255) / 256);
+	hipLaunchKernelGGL(k_tvf_store, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), A.n, X,
+					   reinterpret_cast<float2*>(d_field));
 	return check_launch();
 }
 

@@ -215,10 +215,25 @@ int ebo_count_image_device(ebo_ctx* ctx, int mode, const void* d_aux, double* d_
  * fixed point's value.  field_out: host float32 [image_h][image_w][2] (may be NULL);
  * fixed_xy: host [n_patches][2] (may be NULL).  The field also stays on the device:
  * ebo_count_image(ctx, EBO_COUNT_FIELD, NULL, image) then is R4 (compensateEvents) end to end.
- * interpolateMotionField's per-pixel TV smoothing (:144-241) is not built. */
+ * ebo_interpolate_motion_field applies interpolateMotionField's TV smoothing to it. */
 int ebo_init_motion_field(ebo_ctx* ctx, int64_t timestamp, int use_average, int n_patches,
 						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
 						  float* field_out, int32_t* n_fixed, int32_t* fixed_xy);
+
+/* tracker::FeatureDetector::interpolateMotionField (feature_detector.cpp:144-241) after its
+ * initMotionField call, i.e. on the field ebo_init_motion_field left on the device: if
+ * cv::norm(field) > 0 (:152), the per-pixel problem of :154-214 (totalVarianceFunctor, weight 1,
+ * between every pixel and its right / lower neighbour for x < w-1, y < h-1; HuberLoss(1e-5) when
+ * use_l1 = DetectorParams::useL1; fixed points constant) is solved by the same trust-region LM
+ * as ceres::Solve with the options of :216-222 (opts == NULL) and the field is overwritten with
+ * the result rounded to float32 (:230-239).  All per-pixel work runs on the device; the linear
+ * solve of each LM iteration is a conjugate-gradient run to 1e-13 relative residual.
+ * field_out: host float32 [image_h][image_w][2] (may be NULL; the field stays resident for
+ * ebo_count_image(EBO_COUNT_FIELD)).  cg_iterations (may be NULL): total CG iterations.
+ * EBO_ERR_STATE without a prior ebo_init_motion_field; EBO_ERR_RANGE for a fixed point at pixel
+ * (w-1, h-1), which is no parameter block of that problem (the reference aborts inside Ceres). */
+int ebo_interpolate_motion_field(ebo_ctx* ctx, int use_l1, const ebo_solver_opts* opts, float* field_out,
+								 ebo_summary* summary, int32_t* cg_iterations);
 
 /* R2 in one call: set window, solve, final warped count image.
  * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */

@@ -180,6 +180,15 @@ int orc_init_motion_field(int w, int h, double scale, int use_average, int n_pat
 						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
 						  int64_t timestamp, float* field, int32_t* n_fixed, int32_t* fixed_xy);
 
+/* FeatureDetector::interpolateMotionField after its initMotionField call
+ * (feature_detector.cpp:149-240): the per-pixel TV problem (weight 1; HuberLoss(1e-5) when
+ * use_l1), fixed points constant, Ceres defaults when opts == NULL.  field is read as
+ * initMotionField left it and overwritten.  -2: a fixed point at pixel (w-1, h-1), which is
+ * no parameter block of the reference's problem (Ceres aborts there). */
+int orc_interpolate_motion_field(int w, int h, int use_l1, float* field, int n_fixed,
+								 const int32_t* fixed_xy, const orc_solver_opts* opts,
+								 orc_summary* sum);
+
 /* Patch::integrateEvents (patch.cpp:65-85). ev in deque order (front = newest).
  * nabla [int(rh)][int(rw)]. */
 int orc_patch_integrate(const orc_event* ev, size_t n, double rx, double ry,

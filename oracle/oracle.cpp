@@ -467,6 +467,14 @@ void tvEval(double w, const double* x, const double* y, double* r, double* jx,
 	}
 }
 
+// One row of a block-sparse Jacobian: at most 4 (column, value) entries.
+struct JRow
+{
+	int c[4];
+	double v[4];
+	int nnz;
+};
+
 struct Problem
 {
 	const Window* win = nullptr;
@@ -512,12 +520,7 @@ struct Problem
 	// Evaluates cost = 1/2 sum rho(|f_i|^2), loss-corrected residuals and (when
 	// J != nullptr) the loss-corrected Jacobian as dense rows x ncols... kept
 	// block-sparse: each row stores 4 (col,val) slots.
-	struct Row
-	{
-		int c[4];
-		double v[4];
-		int nnz;
-	};
+	using Row = JRow;
 
 	void evaluate(const double* xFull, double* cost, std::vector<double>* res,
 				  std::vector<Row>* jac)
@@ -603,17 +606,23 @@ struct Problem
 	}
 };
 
-// Symmetric positive-definite solve by Cholesky on a dense matrix, loops
-// restricted to the band.  Returns false when a pivot is not positive.
+// Symmetric positive-definite solve by Cholesky, lower band storage:
+// entry (i, j), i - band <= j <= i, lives at A[i * (band + 1) + (j - i + band)].
+// Returns false when a pivot is not positive.
+inline double& bandAt(std::vector<double>& A, int band, int i, int j)
+{
+	return A[static_cast<size_t>(i) * (band + 1) + (j - i + band)];
+}
+
 bool choleskySolve(std::vector<double>& A, int n, int band, std::vector<double>& b)
 {
 	for (int j = 0; j < n; ++j)
 	{
-		double d = A[static_cast<size_t>(j) * n + j];
+		double d = bandAt(A, band, j, j);
 		const int k0 = std::max(0, j - band);
 		for (int k = k0; k < j; ++k)
 		{
-			const double l = A[static_cast<size_t>(j) * n + k];
+			const double l = bandAt(A, band, j, k);
 			d -= l * l;
 		}
 		if (!(d > 0.0) || !std::isfinite(d))
@@ -621,17 +630,17 @@ bool choleskySolve(std::vector<double>& A, int n, int band, std::vector<double>&
 			return false;
 		}
 		const double ljj = std::sqrt(d);
-		A[static_cast<size_t>(j) * n + j] = ljj;
+		bandAt(A, band, j, j) = ljj;
 		const int i1 = std::min(n - 1, j + band);
 		for (int i = j + 1; i <= i1; ++i)
 		{
-			double s = A[static_cast<size_t>(i) * n + j];
+			double s = bandAt(A, band, i, j);
 			const int kk0 = std::max(0, i - band);
 			for (int k = std::max(k0, kk0); k < j; ++k)
 			{
-				s -= A[static_cast<size_t>(i) * n + k] * A[static_cast<size_t>(j) * n + k];
+				s -= bandAt(A, band, i, k) * bandAt(A, band, j, k);
 			}
-			A[static_cast<size_t>(i) * n + j] = s / ljj;
+			bandAt(A, band, i, j) = s / ljj;
 		}
 	}
 	for (int i = 0; i < n; ++i)
@@ -639,18 +648,18 @@ bool choleskySolve(std::vector<double>& A, int n, int band, std::vector<double>&
 		double s = b[i];
 		for (int k = std::max(0, i - band); k < i; ++k)
 		{
-			s -= A[static_cast<size_t>(i) * n + k] * b[k];
+			s -= bandAt(A, band, i, k) * b[k];
 		}
-		b[i] = s / A[static_cast<size_t>(i) * n + i];
+		b[i] = s / bandAt(A, band, i, i);
 	}
 	for (int i = n - 1; i >= 0; --i)
 	{
 		double s = b[i];
 		for (int k = i + 1; k <= std::min(n - 1, i + band); ++k)
 		{
-			s -= A[static_cast<size_t>(k) * n + i] * b[k];
+			s -= bandAt(A, band, k, i) * b[k];
 		}
-		b[i] = s / A[static_cast<size_t>(i) * n + i];
+		b[i] = s / bandAt(A, band, i, i);
 	}
 	return true;
 }
@@ -659,7 +668,8 @@ bool choleskySolve(std::vector<double>& A, int n, int band, std::vector<double>&
 // (TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy,
 // TrustRegionStepEvaluator); options as feature_detector.cpp:401-410.
 // x is the full [2P] vector; only columns of the reduced problem move.
-int minimize(Problem& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
+template <class PB>
+int minimize(PB& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 {
 	const int n = pb.ncols;
 	const int nFull = static_cast<int>(pb.col.size());
@@ -684,7 +694,7 @@ int minimize(Problem& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 
 	std::vector<double> xcur(x, x + nFull), xcand(nFull), xbest(x, x + nFull);
 	std::vector<double> f, scale(n, 1.0), grad(n), diag(n), lmDiag(n), step(n), delta(n);
-	std::vector<Problem::Row> J;
+	std::vector<JRow> J;
 	double xCost = 0.0;
 
 	auto evalJac = [&](void) {
@@ -787,7 +797,7 @@ int minimize(Problem& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 			}
 		}
 	}
-	std::vector<double> H(static_cast<size_t>(n) * n);
+	std::vector<double> H(static_cast<size_t>(n) * (band + 1));
 
 	for (;;)
 	{
@@ -845,13 +855,16 @@ int minimize(Problem& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 				step[J[r].c[a]] += J[r].v[a] * f[r];
 				for (int b = 0; b < J[r].nnz; ++b)
 				{
-					H[static_cast<size_t>(J[r].c[a]) * n + J[r].c[b]] += J[r].v[a] * J[r].v[b];
+					if (J[r].c[b] <= J[r].c[a])
+					{
+						bandAt(H, band, J[r].c[a], J[r].c[b]) += J[r].v[a] * J[r].v[b];
+					}
 				}
 			}
 		}
 		for (int c = 0; c < n; ++c)
 		{
-			H[static_cast<size_t>(c) * n + c] += lmDiag[c] * lmDiag[c];
+			bandAt(H, band, c, c) += lmDiag[c] * lmDiag[c];
 		}
 		bool valid = choleskySolve(H, n, band, step);
 		if (valid)
@@ -1070,6 +1083,154 @@ void solveWindow(const Window& w, const orc_solver_opts& o, double* flows,
 	{
 		*sum = total;
 	}
+}
+
+// The per-pixel smoothing problem of FeatureDetector::interpolateMotionField
+// (feature_detector.cpp:154-214): one 2-parameter block per pixel, blocks
+// totalVarianceFunctor(weight 1) between (y,x)-(y,x+1) and (y,x)-(y+1,x) for y < H-1,
+// x < W-1 (:170-204), loss none or HuberLoss(1e-5) (useL1), fixed points constant
+// (:206-214).  As ceres::Problem reduces it: constant blocks leave the parameter vector,
+// residual blocks between two constants leave the cost, pixel (H-1, W-1) is in no block.
+// Columns are component-major over the free pixels in raster order (a block-diagonal
+// normal matrix of band <= W); Ceres' own fill-reducing order is not reproducible here,
+// so the last bits are unpinned exactly as for the patch solve.
+struct FieldProblem
+{
+	int W = 0, H = 0;
+	bool l1 = false;
+	std::vector<char> fixed;  // per pixel
+	std::vector<int> col;	  // 2 * pixel + c -> column or -1
+	std::vector<int> eP, eQ;  // residual blocks kept, creation order
+	int ncols = 0, nrows = 0;
+	int evalsCost = 0, evalsJac = 0;
+
+	void build(int w, int h, bool useL1, int nFixed, const int32_t* fixedXy)
+	{
+		W = w;
+		H = h;
+		l1 = useL1;
+		fixed.assign(static_cast<size_t>(W) * H, 0);
+		for (int i = 0; i < nFixed; ++i)
+		{
+			fixed[static_cast<size_t>(fixedXy[2 * i + 1]) * W + fixedXy[2 * i]] = 1;
+		}
+		std::vector<char> used(static_cast<size_t>(W) * H, 0);
+		for (int y = 0; y < H - 1; ++y)
+		{
+			for (int x = 0; x < W - 1; ++x)
+			{
+				const int p = y * W + x;
+				used[p] = used[p + 1] = used[p + W] = 1;
+				if (!(fixed[p] && fixed[p + 1]))
+				{
+					eP.push_back(p);
+					eQ.push_back(p + 1);
+				}
+				if (!(fixed[p] && fixed[p + W]))
+				{
+					eP.push_back(p);
+					eQ.push_back(p + W);
+				}
+			}
+		}
+		int nFree = 0;
+		std::vector<int> freeIdx(static_cast<size_t>(W) * H, -1);
+		for (int p = 0; p < W * H; ++p)
+		{
+			if (used[p] && !fixed[p])
+			{
+				freeIdx[p] = nFree++;
+			}
+		}
+		col.assign(static_cast<size_t>(W) * H * 2, -1);
+		for (int p = 0; p < W * H; ++p)
+		{
+			if (freeIdx[p] >= 0)
+			{
+				col[2 * p] = freeIdx[p];
+				col[2 * p + 1] = freeIdx[p] + nFree;
+			}
+		}
+		ncols = 2 * nFree;
+		nrows = 2 * static_cast<int>(eP.size());
+	}
+
+	void evaluate(const double* xFull, double* cost, std::vector<double>* res,
+				  std::vector<JRow>* jac)
+	{
+		double c = 0.0;
+		if (res)
+		{
+			res->assign(nrows, 0.0);
+		}
+		if (jac)
+		{
+			jac->assign(nrows, JRow());
+			evalsJac++;
+		}
+		else
+		{
+			evalsCost++;
+		}
+		for (size_t e = 0; e < eP.size(); ++e)
+		{
+			const int p = eP[e], q = eQ[e];
+			double r[2], jx[4], jy[4];
+			tvEval(1.0, xFull + 2 * p, xFull + 2 * q, r, jac ? jx : nullptr, jac ? jy : nullptr);
+			const double s = r[0] * r[0] + r[1] * r[1];
+			double sr = 1.0;
+			if (l1)
+			{
+				double rho[3];
+				huber(1e-5, s, rho);  // :182,187
+				c += 0.5 * rho[0];
+				sr = std::sqrt(rho[1]);
+			}
+			else
+			{
+				c += 0.5 * s;
+			}
+			for (int k = 0; k < 2; ++k)
+			{
+				if (res)
+				{
+					(*res)[2 * e + k] = r[k] * sr;
+				}
+				if (jac)
+				{
+					JRow& row = (*jac)[2 * e + k];
+					row.nnz = 0;
+					if (col[2 * p + k] >= 0)
+					{
+						row.c[row.nnz] = col[2 * p + k];
+						row.v[row.nnz++] = jx[k * 2 + k] * sr;
+					}
+					if (col[2 * q + k] >= 0)
+					{
+						row.c[row.nnz] = col[2 * q + k];
+						row.v[row.nnz++] = jy[k * 2 + k] * sr;
+					}
+				}
+			}
+		}
+		*cost = c;
+	}
+};
+
+// cv::norm(motionField_) > 0 (:152) on the CV_64FC2 matrix whose first half of every row
+// holds the float pairs written through at<cv::Vec2f>: each pixel's two floats are read
+// back as one double and squared (a pair with a zero second float is a subnormal double
+// whose square underflows to zero).
+bool fieldNormPositive(const float* field, size_t pixels)
+{
+	double acc = 0.0;
+	for (size_t i = 0; i < pixels; ++i)
+	{
+		double v;
+		std::memcpy(&v, field + 2 * i, sizeof(double));
+		acc += v * v;
+	}
+	return std::sqrt(acc) > 0.0;
 }
 
 // feature_detector.cpp:433-463.  round() = half away from zero (F7).
@@ -1506,6 +1667,68 @@ int orc_init_motion_field(int w, int h, double scale, int use_average, int n_pat
 			fixed_xy[2 * i] = fx[i];
 			fixed_xy[2 * i + 1] = fy[i];
 		}
+	}
+	return 0;
+}
+
+// FeatureDetector::interpolateMotionField after its initMotionField call
+// (feature_detector.cpp:149-240).  field: float32 [h][w][2] as initMotionField left it,
+// overwritten with the smoothed field (:230-239).  opts == NULL: ceres::Solver::Options
+// defaults with :216-222 applied (50 iterations, tolerances 1e-6 / 1e-10 / 1e-8, monotonic).
+int orc_interpolate_motion_field(int w, int h, int use_l1, float* field, int n_fixed,
+								 const int32_t* fixed_xy, const orc_solver_opts* opts,
+								 orc_summary* sum)
+{
+	if (!field || w < 2 || h < 2 || n_fixed < 0 || (n_fixed > 0 && !fixed_xy))
+	{
+		return -1;
+	}
+	for (int i = 0; i < n_fixed; ++i)
+	{
+		const int x = fixed_xy[2 * i], y = fixed_xy[2 * i + 1];
+		if (x < 0 || x >= w || y < 0 || y >= h)
+		{
+			return -1;
+		}
+		if (x == w - 1 && y == h - 1)
+		{
+			return -2;  // not a parameter block of the problem: Ceres aborts (:208)
+		}
+	}
+	orc_summary local;
+	std::memset(&local, 0, sizeof(local));
+	const size_t pixels = static_cast<size_t>(w) * h;
+	if (fieldNormPositive(field, pixels))
+	{
+		orc_solver_opts o;
+		if (opts)
+		{
+			o = *opts;
+		}
+		else
+		{
+			orc_default_solver(&o);
+			o.use_nonmonotonic = 0;
+			o.function_tolerance = 1e-6;
+			o.gradient_tolerance = 1e-10;
+			o.parameter_tolerance = 1e-8;
+		}
+		std::vector<double> mf(pixels * 2);
+		for (size_t i = 0; i < pixels * 2; ++i)
+		{
+			mf[i] = field[i];  // :159-168
+		}
+		FieldProblem pb;
+		pb.build(w, h, use_l1 != 0, n_fixed, fixed_xy);
+		minimize(pb, o, mf.data(), &local);
+		for (size_t i = 0; i < pixels * 2; ++i)
+		{
+			field[i] = static_cast<float>(mf[i]);  // :230-239
+		}
+	}
+	if (sum)
+	{
+		*sum = local;
 	}
 	return 0;
 }

@@ -315,3 +315,16 @@ def init_motion_field(w, h, timestamp, trajectories, use_average=True, scale=1e-
         fixed.ctypes.data_as(C.c_void_p))
     assert rc == 0
     return field, fixed[: nfix.value].copy()
+
+
+def interpolate_motion_field(field, fixed, use_l1=False, opts=None):
+    """FeatureDetector::interpolateMotionField after its initMotionField call.
+    field float32 [h][w][2] (copied), fixed int32 [n][2] (x, y).  Returns (field, summary, rc)."""
+    out = np.ascontiguousarray(field, dtype=np.float32).copy()
+    h, w = out.shape[:2]
+    fx = np.ascontiguousarray(fixed, dtype=np.int32).reshape(-1, 2)
+    s = Summary()
+    rc = lib().orc_interpolate_motion_field(
+        int(w), int(h), int(bool(use_l1)), out.ctypes.data_as(C.c_void_p), len(fx),
+        fx.ctypes.data_as(C.c_void_p), C.byref(opts) if opts is not None else None, C.byref(s))
+    return out, s, rc
