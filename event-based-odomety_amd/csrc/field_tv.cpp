@@ -69,7 +69,8 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 	const double cgTol = tolEnv ? std::atof(tolEnv) : 1e-13;
 	const char* capEnv = std::getenv("EBO_TVF_CG_MAX");
 	const int cgMax = capEnv ? std::atoi(capEnv) : 200000;
-	const int cgChunk = 32;
+	const char* chunkEnv = std::getenv("EBO_TVF_CG_CHUNK");
+	const int cgChunk = chunkEnv ? std::max(2, std::atoi(chunkEnv) & ~1) : 32;
 
 	auto fail = [&](const char* what) {
 		*err = std::string("field TV: ") + what;
@@ -107,6 +108,42 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 		}
 		return read_scal(A, s, sc, err);
 	};
+
+	// One chunk of CG iterations as a graph: iterations after the first chunk differ only
+	// in the parity of their index (which direction buffer is old), and a chunk is even.
+	// The kernels take every pointer from A, which is fixed for this call.
+	struct GraphHolder
+	{
+		hipGraph_t g = nullptr;
+		hipGraphExec_t e = nullptr;
+		~GraphHolder()
+		{
+			if (e)
+			{
+				hipGraphExecDestroy(e);
+			}
+			if (g)
+			{
+				hipGraphDestroy(g);
+			}
+		}
+	} gh;
+	hipGraphExec_t chunkGraph = nullptr;
+	const char* graphEnv = std::getenv("EBO_TVF_GRAPH");
+	if (!graphEnv || std::atoi(graphEnv) != 0)
+	{
+		if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess)
+		{
+			const int lrc = launch_tvf_cg_iters(A, cgChunk, cgChunk, s);
+			const hipError_t ce = hipStreamEndCapture(s, &gh.g);
+			if (lrc == 0 && ce == hipSuccess && gh.g &&
+				hipGraphInstantiate(&gh.e, gh.g, nullptr, nullptr, 0) == hipSuccess)
+			{
+				chunkGraph = gh.e;
+			}
+		}
+		(void)hipGetLastError();  // a failed capture falls back to plain launches
+	}
 
 	// Iteration zero.
 	rc = linearize(A.x, o.jacobi_scaling ? 1 : 2, 0);
@@ -177,7 +214,14 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 		int done = 0;
 		while (done < cgMax)
 		{
-			if (launch_tvf_cg_iters(A, done, cgChunk, s))
+			if (done > 0 && chunkGraph)
+			{
+				if (hipGraphLaunch(chunkGraph, s) != hipSuccess)
+				{
+					return fail("cg graph launch");
+				}
+			}
+			else if (launch_tvf_cg_iters(A, done, cgChunk, s))
 			{
 				return fail("cg launch");
 			}

@@ -182,9 +182,10 @@ class FeatureDetector
 		check(ebo_count_image(ctx_, EBO_COUNT_INTEGRATED, nullptr, integratedEventImage_.ptr()));
 	}
 
-	// feature_detector.cpp:243-296, warp loop; the per-pixel motion field is whatever
-	// setMotionField() installed (initMotionField/interpolateMotionField, which derive
-	// it from tracked feature trajectories, are outside this path).
+	// feature_detector.cpp:243-296.  With patch trajectories installed (setPatchTrajectories)
+	// this is the reference's sequence: mid timestamp (:247-248), interpolateMotionField or
+	// initMotionField by optimizeFlowTV (:253-260), warp loop (:268-295).  Without
+	// trajectories the field installed by setMotionField() is used as it is.
 	void compensateEvents(const std::list<common::EventSample>& events)
 	{
 		if (events.empty())
@@ -192,6 +193,19 @@ class FeatureDetector
 			return;
 		}
 		lastCompensation = events.back().timestamp;  // :250
+		if (!trajectories_.empty())
+		{
+			const auto timestamp = common::timestamp_t(static_cast<int32_t>(
+				(events.front().timestamp + events.back().timestamp).count() * 0.5));
+			if (params_.optimizeFlowTV)
+			{
+				interpolateMotionField(timestamp);
+			}
+			else
+			{
+				initMotionField(timestamp);
+			}
+		}
 		const std::vector<ebo_event> ev = common::toEboEvents(events);
 		check(ebo_set_window(ctx_, ev.data(), ev.size()));
 		check(ebo_count_image(ctx_, EBO_COUNT_FIELD, motionField_.data(), compensatedEventImage_.ptr()));
@@ -221,6 +235,17 @@ class FeatureDetector
 									static_cast<int>(trajectories_.size()), off.data(), xy.data(), tt.data(),
 									motionField_.data(), nullptr, nullptr));
 	}
+
+	// feature_detector.cpp:144-241: initMotionField, then the per-pixel TV problem (useL1
+	// selects HuberLoss(1e-5)) solved on the device; getLastFieldSummary() is what the
+	// reference logs as summary.BriefReport() (:228).
+	void interpolateMotionField(const common::timestamp_t timestamp)
+	{
+		initMotionField(timestamp);
+		check(ebo_interpolate_motion_field(ctx_, params_.useL1 ? 1 : 0, nullptr, motionField_.data(),
+										   &lastFieldSummary_, nullptr));
+	}
+	const ebo_summary& getLastFieldSummary() const { return lastFieldSummary_; }
 
 	// float32 [height][width][2], the at<cv::Vec2f> view of the reference's motionField_
 	void setMotionField(const std::vector<float>& field)
@@ -256,6 +281,7 @@ class FeatureDetector
 	}
 
 	DetectorParams params_;
+	ebo_summary lastFieldSummary_{};
 	ebo_ctx* ctx_ = nullptr;
 	int numPatchesX_ = 0, numPatchesY_ = 0;
 	Mat64 compensatedEventImage_;

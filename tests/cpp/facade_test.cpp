@@ -149,6 +149,64 @@ int main()
 	}
 	EXPECT_TRUE(sameF);
 
+	// compensateEvents as the reference runs it (feature_detector.cpp:243-296): trajectories of
+	// tracked patches -> interpolateMotionField (optimizeFlowTV = true by default) -> warp loop
+	{
+		std::vector<tracker::FeatureDetector::Trajectory> trajs;
+		std::vector<size_t> off(1, 0);
+		std::vector<double> txy;
+		std::vector<int64_t> tts;
+		const int64_t tMid = static_cast<int32_t>((window.front().timestamp + window.back().timestamp).count() * 0.5);
+		for (int k = 0; k < 9; ++k)
+		{
+			tracker::FeatureDetector::Trajectory tr;
+			const double vx = 0.3 * (k % 3 - 1) + 0.05 * k, vy = 0.2 * (k / 3 - 1);  // px per ms
+			for (int i = -2; i <= 2; ++i)
+			{
+				const int64_t t = tMid + 100 + 20000 * i;
+				common::Sample<common::Point2d> smp;
+				smp.value.x = 30.0 + 22.0 * k + vx * 20.0 * i;
+				smp.value.y = 25.0 + 15.0 * k + vy * 20.0 * i;
+				smp.timestamp = common::timestamp_t(t);
+				tr.push_back(smp);
+				txy.push_back(smp.value.x);
+				txy.push_back(smp.value.y);
+				tts.push_back(t);
+			}
+			trajs.push_back(tr);
+			off.push_back(tts.size());
+		}
+		detector.setPatchTrajectories(trajs);
+		detector.compensateEvents(window);
+		std::vector<float> ofield(240 * 180 * 2);
+		std::vector<int32_t> ofix(2 * 9);
+		int32_t nfix = 0;
+		orc_init_motion_field(240, 180, 1e-3, 1, 9, off.data(), txy.data(), tts.data(), tMid, ofield.data(), &nfix,
+							  ofix.data());
+		EXPECT_TRUE(nfix == 9);
+		orc_summary fs;
+		orc_interpolate_motion_field(240, 180, 0, ofield.data(), nfix, ofix.data(), nullptr, &fs);
+		EXPECT_TRUE(detector.getLastFieldSummary().iterations == fs.iterations);
+		EXPECT_NEAR(detector.getLastFieldSummary().final_cost, fs.final_cost, 1e-9 * fs.final_cost);
+		double worst = 0;
+		for (size_t i = 0; i < ofield.size(); ++i)
+		{
+			worst = std::max(worst, std::fabs(static_cast<double>(ofield[i]) - detector.getMotionField()[i]));
+		}
+		EXPECT_TRUE(worst < 2e-7);  // float32 storage: at most one ulp apart
+		// the count image through the facade's own field is bit exact
+		std::vector<double> oimgF(240 * 180);
+		orc_compensate_events_field(oev.data(), oev.size(), 240, 180, 1e-3, detector.getMotionField().data(),
+									oimgF.data());
+		bool sameT = true;
+		for (int i = 0; i < 240 * 180; ++i)
+		{
+			sameT = sameT && detector.getCompensatedEventImage().ptr()[i] == oimgF[i];
+		}
+		EXPECT_TRUE(sameT);
+		detector.setPatchTrajectories({});
+	}
+
 	// ---- contrastFunctor with the reference's constructor ---------------------------------
 	const tracker::Rect2i rect(20, 40, 20, 20);
 	std::list<common::EventSample> patchEvents;
