@@ -195,6 +195,20 @@ def main():
             "gbs_algorithmic": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9,
             "hbm_frac": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }
+        # un-warped count image (integrateEvents, feature_detector.cpp:466-482)
+        ctx.count_image_device(ebo.COUNT_INTEGRATED, 0, d_img.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(10):
+            ctx.count_image_device(ebo.COUNT_INTEGRATED, 0, d_img.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / 10
+        extras["count_image_integrated"] = {
+            "ms": cms, "mevents_per_s": n_events / (cms * 1e-3) / 1e6,
+            "gbs_algorithmic": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9,
+            "hbm_frac": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
         # single-window latency (one 50k-event window, one launch)
         c1 = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
                          patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,

@@ -63,6 +63,8 @@ struct ebo_ctx
 	double* d_image = nullptr;
 	void* d_aux = nullptr;
 	size_t aux_cap = 0;
+	unsigned long long* d_count_ovf = nullptr;  // k_count_bands' overflow list
+	size_t count_ovf_cap = 0;
 	int32_t* d_stats = nullptr;
 	void* d_scratch = nullptr;  // patch-integrate staging
 	size_t scratch_cap = 0;
@@ -598,6 +600,33 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	L.d_counts = c->d_counts;
 	L.d_image = d_image;
 	L.c = make_consts(c);
+	L.d_overflow = nullptr;
+	if (L.impl < 0 || L.impl == 2)
+	{
+		size_t total = 0;
+		for (const WindowInfo& wi : c->windows)
+		{
+			total += wi.n_events;
+		}
+		const size_t need = (total + 1) * sizeof(unsigned long long);
+		if (need > c->count_ovf_cap)
+		{
+			if (c->d_count_ovf)
+			{
+				hipFree(c->d_count_ovf);
+				c->d_count_ovf = nullptr;
+				c->count_ovf_cap = 0;
+			}
+			const size_t cap = std::max(need, (static_cast<size_t>(c->prm.max_events) + 1) * sizeof(unsigned long long));
+			int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_count_ovf), cap), "hipMalloc count overflow list");
+			if (rc)
+			{
+				return rc;
+			}
+			c->count_ovf_cap = cap;
+		}
+		L.d_overflow = c->d_count_ovf;
+	}
 	if (launch_count_image(L, c->stream))
 	{
 		return c->hip(hipGetLastError(), "count launch");
@@ -1024,6 +1053,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_out);
 	hipFree(c->d_partials);
 	hipFree(c->d_counts);
+	hipFree(c->d_count_ovf);
 	hipFree(c->d_image);
 	hipFree(c->d_aux);
 	hipFree(c->d_stats);

@@ -1143,12 +1143,20 @@ __global__ void k_count_scatter(const uint64_t* __restrict__ events, const Unit*
 template <bool U16>
 __global__ void __launch_bounds__(1024) k_count_window_lds(
 	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
-	int mode, const void* __restrict__ aux, int rowsPerBand, double* __restrict__ image,
+	int mode, const void* __restrict__ aux, int rowsPerBand, int nWindows, double* __restrict__ image,
 	EvalConsts c)
 {
 	extern __shared__ unsigned int cnt[];
-	const int w = blockIdx.y;
-	const int row0 = blockIdx.x * rowsPerBand;
+	// 1-D grid; consecutive workgroup ids go round-robin over the 8 XCDs, so the bands of one
+	// window take consecutive slots of ONE XCD: the second band's event reads hit that L2.
+	const int nBands = (c.image_h + rowsPerBand - 1) / rowsPerBand;
+	const int slot = blockIdx.x >> 3;
+	const int w = (slot / nBands) * 8 + (blockIdx.x & 7);
+	if (w >= nWindows)
+	{
+		return;
+	}
+	const int row0 = (slot % nBands) * rowsPerBand;
 	const int rows = min(rowsPerBand, c.image_h - row0);
 	const int W = c.image_w;
 	const int npx = rows * W;
@@ -1278,6 +1286,223 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
 			out[p] = static_cast<double>(v);
 		}
+	}
+}
+
+// Patch-row bands (impl 2): workgroup = (band of whole patch rows, window).  Events are
+// stored unit by unit in patch order, so the events that START in a band are one contiguous
+// range: the workgroup streams only those (no re-reads by other bands, any image size),
+// counts the ones whose warped position stays inside the band in LDS and appends the rare
+// ones that leave the band (but stay inside the image) to an overflow list, which
+// k_count_overflow adds with f64 atomics after every band has stored its rows.  The stray
+// unit of the window (events outside the sensor) is streamed by band 0.  HBM traffic = events
+// once + image once, for any flow; integer adds commute => bit-exact.
+template <bool U16>
+__global__ void __launch_bounds__(512) k_count_bands(
+	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
+	int mode, const void* __restrict__ aux, int patchRowsPerBand, int nRegular, double* __restrict__ image,
+	unsigned long long* __restrict__ ovf /* [0] = count, then entries */, EvalConsts c)
+{
+	extern __shared__ unsigned int cnt[];
+	const int w = blockIdx.y;
+	const int band = blockIdx.x;
+	// bands 0..nRegular-1: patchRowsPerBand whole patch rows each, over patch rows [0, npy-1);
+	// then the last patch row (which absorbs the remainder of the image height and can be
+	// almost twice as tall) in sub-bands of at most patchRowsPerBand * patch_h rows.
+	int pr0, pr1, row0, row1;
+	bool reportsOutside = true;  // this workgroup appends the hits outside [regionRow0, regionRow1)
+	if (band < nRegular)
+	{
+		pr0 = band * patchRowsPerBand;
+		pr1 = min(pr0 + patchRowsPerBand, c.npy - 1);
+		row0 = pr0 * c.patch_h;
+		row1 = pr1 * c.patch_h;
+	}
+	else
+	{
+		pr0 = c.npy - 1;
+		pr1 = c.npy;
+		const int sub = band - nRegular;
+		row0 = pr0 * c.patch_h + sub * patchRowsPerBand * c.patch_h;
+		row1 = min(row0 + patchRowsPerBand * c.patch_h, c.image_h);
+		reportsOutside = sub == 0;
+	}
+	// rows another workgroup streaming the same events counts in its own LDS
+	const int regionRow0 = pr0 * c.patch_h;
+	const int regionRow1 = (pr1 == c.npy) ? c.image_h : pr1 * c.patch_h;
+	const int rows = row1 - row0;
+	const int W = c.image_w;
+	const int npx = rows * W;
+	const int nWords = U16 ? (npx + 1) >> 1 : npx;
+	for (int i = threadIdx.x; i < nWords; i += blockDim.x)
+	{
+		cnt[i] = 0u;
+	}
+	__syncthreads();
+	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
+	const int P = c.npx * c.npy;
+	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
+	const double* flows = static_cast<const double*>(aux);
+	constexpr int kInFlight = 8;
+	// pass 0: the band's own patch units; pass 1 (band 0 only): the stray unit
+	for (int pass = 0; pass < (band == 0 ? 2 : 1); ++pass)
+	{
+		int ui = pass == 0 ? pr0 * c.npx : P;
+		const int uLast = pass == 0 ? pr1 * c.npx - 1 : P;
+		const uint32_t evBegin = wu[ui].ev_off;
+		const uint32_t evEnd = wu[uLast].ev_off + wu[uLast].n_ev;
+		uint32_t uEnd = wu[ui].ev_off + wu[ui].n_ev;
+		double m0 = 0.0, m1 = 0.0;
+		int dtWin = wu[ui].dt_win;
+		const bool stray = pass == 1;
+		if (mode == 1 && !stray)
+		{
+			m0 = flows[2 * wu[ui].flow_idx];
+			m1 = flows[2 * wu[ui].flow_idx + 1];
+		}
+		for (uint32_t eb = evBegin + threadIdx.x; eb < evEnd; eb += kInFlight * blockDim.x)
+		{
+			uint64_t recs[kInFlight];
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const uint32_t ek = eb + k * blockDim.x;
+				recs[k] = (ek < evEnd) ? events[ek] : 0ull;
+			}
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const uint32_t e = eb + k * blockDim.x;
+				// every lane of the wave walks the same k: the overflow append below is one
+				// atomic per wave (ballot + prefix count), so the tail lanes stay in the loop
+				bool live = e < evEnd;
+				if (live)
+				{
+					while (e >= uEnd)
+					{
+						++ui;
+						uEnd = wu[ui].ev_off + wu[ui].n_ev;
+						dtWin = wu[ui].dt_win;
+						if (mode == 1 && !stray)
+						{
+							m0 = flows[2 * wu[ui].flow_idx];
+							m1 = flows[2 * wu[ui].flow_idx + 1];
+						}
+					}
+				}
+				int x, y, pos, dt;
+				unpack(recs[k], x, y, pos, dt);
+				int nx = x, ny = y;
+				if (live && mode != 0)
+				{
+					if (mode == 1 && stray)
+					{
+						const int px = max(min(x / c.patch_w, c.npx - 1), 0);
+						const int py = max(min(y / c.patch_h, c.npy - 1), 0);
+						m0 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px)];
+						m1 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px) + 1];
+					}
+					if (mode == 2)
+					{
+						live = x >= 0 && x < W && y >= 0 && y < c.image_h;
+						if (live)
+						{
+							const float* field = static_cast<const float*>(aux) +
+												 2 * (static_cast<size_t>(w) * imgSize + static_cast<size_t>(y) * W + x);
+							m0 = static_cast<double>(field[0]);
+							m1 = static_cast<double>(field[1]);
+						}
+					}
+					const double dtw = static_cast<double>(dt + dtWin);
+					const double fx = static_cast<double>(x) + dtw * c.scale * m0;
+					const double fy = static_cast<double>(y) + dtw * c.scale * m1;
+					live = live && convertible(fx) && convertible(fy);
+					if (live)
+					{
+						nx = static_cast<int>(round(fx));
+						ny = static_cast<int>(round(fy));
+					}
+				}
+				live = live && nx >= 0 && nx < W && ny >= 0 && ny < c.image_h;
+				const int ry = ny - row0;
+				const bool inBand = live && ry >= 0 && ry < rows;
+				if (inBand)
+				{
+					const int p = ry * W + nx;
+					if (U16)
+					{
+						atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
+					}
+					else
+					{
+						atomicAdd(&cnt[p], 1u);
+					}
+				}
+				// (a stray event is streamed by this workgroup only; an own event that lands in
+				// another sub-band of the same patch row is counted there)
+				const bool spill = live && !inBand &&
+								   (stray || (reportsOutside && (ny < regionRow0 || ny >= regionRow1)));
+				const unsigned long long spillMask = __ballot(spill);
+				if (spillMask != 0ull)
+				{
+					const int lane = threadIdx.x & 63;
+					const int leader = __ffsll(static_cast<long long>(spillMask)) - 1;
+					unsigned int baseLo = 0u, baseHi = 0u;
+					if (lane == leader)
+					{
+						const unsigned long long b =
+							atomicAdd(ovf, static_cast<unsigned long long>(__popcll(spillMask)));
+						baseLo = static_cast<unsigned int>(b);
+						baseHi = static_cast<unsigned int>(b >> 32);
+					}
+					baseLo = __shfl(baseLo, leader, 64);
+					baseHi = __shfl(baseHi, leader, 64);
+					if (spill)
+					{
+						const unsigned long long base = (static_cast<unsigned long long>(baseHi) << 32) | baseLo;
+						const unsigned long long before = spillMask & ((1ull << lane) - 1ull);
+						ovf[1 + base + __popcll(before)] =
+							static_cast<unsigned long long>(w) * imgSize + static_cast<size_t>(ny) * W + nx;
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W;
+	if (U16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+	{
+		const int pairs = npx >> 1;
+		double2* out2 = reinterpret_cast<double2*>(out);
+		for (int i = threadIdx.x; i < pairs; i += blockDim.x)
+		{
+			const unsigned int v = cnt[i];
+			out2[i] = make_double2(static_cast<double>(v & 0xFFFFu), static_cast<double>(v >> 16));
+		}
+		if ((npx & 1) && threadIdx.x == 0)
+		{
+			out[npx - 1] = static_cast<double>(cnt[pairs] & 0xFFFFu);
+		}
+	}
+	else
+	{
+		for (int p = threadIdx.x; p < npx; p += blockDim.x)
+		{
+			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
+			out[p] = static_cast<double>(v);
+		}
+	}
+}
+
+// Adds the events that left their band (k_count_bands) and re-arms the list.
+__global__ void k_count_overflow(unsigned long long* __restrict__ ovf, double* __restrict__ image)
+{
+	const unsigned long long n = ovf[0];
+	const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+	for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+		 i += stride)
+	{
+		unsafeAtomicAdd(&image[ovf[1 + i]], 1.0);  // global_atomic_add_f64; exact on integer counts
 	}
 }
 
@@ -1701,7 +1926,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		const size_t pxPerBand = u16 ? ldsBytes / 2 : ldsBytes / 4;
 		const int rowsPerBand = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
 		const int bands = rowsPerBand > 0 ? (L.c.image_h + rowsPerBand - 1) / rowsPerBand : 1 << 30;
-		const bool want = L.impl == 1 || (L.impl < 0 && bands <= 4 && L.n_windows * bands >= 64);
+		const bool want = L.impl == 1 || (L.impl < 0 && L.mode != 0 && bands <= 4 && L.n_windows * bands >= 64);
 		if (want && rowsPerBand > 0 && L.n_units_total > 0)
 		{
 			auto kern = u16 ? k_count_window_lds<true> : k_count_window_lds<false>;
@@ -1710,8 +1935,40 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			{
 				return -2;
 			}
-			hipLaunchKernelGGL(kern, dim3(bands, L.n_windows), dim3(1024), lds, s, L.d_events, L.d_units,
-							   L.units_per_window, L.mode, L.d_aux, rowsPerBand, L.d_image, L.c);
+			const int groups = (L.n_windows + 7) / 8;  // 8 windows (one per XCD) x bands slots each
+			hipLaunchKernelGGL(kern, dim3(groups * bands * 8), dim3(1024), lds, s, L.d_events, L.d_units,
+							   L.units_per_window, L.mode, L.d_aux, rowsPerBand, L.n_windows, L.d_image, L.c);
+			return check_launch();
+		}
+	}
+	// Patch-row bands (impl 2): any image size, no event read twice.  The default for the
+	// un-warped image (events never leave their band: 4.3 TB/s at C2, 3.9 at C3, 2.7 at C4);
+	// with warping the events that leave a band cost a random HBM access each, which loses
+	// against the paths above unless the flows are small (selectable, EBO_COUNT_IMPL=2).
+	if ((L.impl == 2 || (L.impl < 0 && L.mode == 0)) && L.d_overflow && L.n_units_total > 0)
+	{
+		const bool u16 = L.max_window_events < 65536;
+		const size_t ldsBytes = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : (L.mode == 0 ? 24 : 76)) * 1024;
+		const size_t rowBytes = static_cast<size_t>(L.c.image_w) * (u16 ? 2 : 4);
+		const int prb = std::max(1, static_cast<int>(ldsBytes / rowBytes) / L.c.patch_h);
+		const int bandRows = prb * L.c.patch_h;
+		const size_t lds = (static_cast<size_t>(bandRows) * rowBytes + 3) & ~size_t(3);
+		auto kern = u16 ? k_count_bands<true> : k_count_bands<false>;
+		if (lds <= 160 * 1024 - 512 && allow_big_lds(kern, lds) == 0)
+		{
+			const int nRegular = (L.c.npy - 1 + prb - 1) / prb;
+			const int tallest = L.c.image_h - (L.c.npy - 1) * L.c.patch_h;
+			const int nSub = (tallest + bandRows - 1) / bandRows;
+			if (L.mode != 0 && hipMemsetAsync(L.d_overflow, 0, 8, s) != hipSuccess)
+			{
+				return -2;
+			}
+			hipLaunchKernelGGL(kern, dim3(nRegular + nSub, L.n_windows), dim3(512), lds, s, L.d_events, L.d_units,
+							   L.units_per_window, L.mode, L.d_aux, prb, nRegular, L.d_image, L.d_overflow, L.c);
+			if (L.mode != 0)
+			{
+				hipLaunchKernelGGL(k_count_overflow, dim3(512), dim3(256), 0, s, L.d_overflow, L.d_image);
+			}
 			return check_launch();
 		}
 	}

@@ -1,6 +1,6 @@
-"""GPU tests of the two count-image implementations (global int atomics vs
-LDS-privatised row bands): both bit-exact against the oracle, on single windows
-and on batches, for all three modes."""
+"""GPU tests of the count-image implementations (0: global int atomics, 1: whole-window LDS
+bands, 2: patch-row LDS bands with an overflow list for events that leave their band): all
+bit-exact against the oracle, on single windows and on batches, for all three modes."""
 import numpy as np
 import pytest
 
@@ -13,8 +13,8 @@ def _prm(orc, c):
                               patch_h=p.patch_h, scale=p.scale, min_events=p.min_events, loss=1)
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "auto"])
-@pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000)])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "auto"])
+@pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000), (4, 2, 60000)])
 def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config, n_windows, n_events):
     if impl == "auto":
         monkeypatch.delenv("EBO_COUNT_IMPL", raising=False)
@@ -46,9 +46,10 @@ def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config,
             assert np.array_equal(again[k], integ[k])
 
 
-def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypatch):
+@pytest.mark.parametrize("impl", ["1", "2"])
+def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypatch, impl):
     """16-bit packed counters are only used below 65536 events per window."""
-    monkeypatch.setenv("EBO_COUNT_IMPL", "1")
+    monkeypatch.setenv("EBO_COUNT_IMPL", impl)
     cfg = synth.CONFIGS[2]
     ev, _ = synth.make_window(2, n_events=90000)
     ev["x"][:70000] = 11  # 70000 events on ONE pixel: would overflow a 16-bit counter
@@ -59,3 +60,28 @@ def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypa
         img = c.count_image(ebo.COUNT_INTEGRATED)[0]
         assert img[13, 11] >= 70000
         assert np.array_equal(img, orc.integrate_events(ev, 240, 180))
+
+
+@pytest.mark.parametrize("lds_kb", ["12", "24", "150"])
+def test_patch_row_bands_any_band_size_and_large_flows(ebo, orc, synth, monkeypatch, lds_kb):
+    """impl 2 with bands of one patch row up to the whole image, flows large enough that most
+    events leave their band (overflow list) or the image."""
+    monkeypatch.setenv("EBO_COUNT_IMPL", "2")
+    monkeypatch.setenv("EBO_COUNT_LDS_KB", lds_kb)
+    cfg = synth.CONFIGS[2]
+    ev, offsets, gt = synth.make_stream(2, 5, n_events=20000)
+    ev["x"][3] = -2  # stray events, warped back inside by the flow of their clamped patch
+    ev["y"][3] = 100
+    ev["y"][7] = 185
+    with ebo.Context(image_w=240, image_h=180, patch_w=30, patch_h=22, loss=ebo.LOSS_VARIANCE,
+                     max_windows=5, max_events=len(ev)) as c:
+        c.set_windows(ev, offsets)
+        prm = _prm(orc, c)
+        rng = np.random.RandomState(3)
+        flows = rng.uniform(-8, 8, (5, c.P, 2))
+        warped = c.count_image(ebo.COUNT_WARPED, flows)
+        integ = c.count_image(ebo.COUNT_INTEGRATED)
+        for k in range(5):
+            sub = ev[int(offsets[k]):int(offsets[k + 1])]
+            assert np.array_equal(warped[k], orc.final_count_image(sub, prm, flows[k]))
+            assert np.array_equal(integ[k], orc.integrate_events(sub, 240, 180))
