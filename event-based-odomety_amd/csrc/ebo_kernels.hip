@@ -1133,6 +1133,53 @@ __global__ void k_count_scatter(const uint64_t* __restrict__ events, const Unit*
 	}
 }
 
+// Destination pixel of one event for the count images; MODE = EBO_COUNT_*.  Returns false
+// when the event contributes nothing (outside the image, or a coordinate the reference's
+// int conversion does not define).  Straight-line code: every lane of a wave runs it.
+//   MODE 1: newP = round(p + (t_ref - t) * scale * mf[patch])      feature_detector.cpp:443-451
+//   MODE 2: same with the float32 field at the event's own pixel   :276-285
+template <int MODE>
+__device__ __forceinline__ bool count_target(uint64_t rec, bool live, int dtWin, double m0, double m1,
+											 const float* __restrict__ field /* window's field */,
+											 const EvalConsts& c, int& nx, int& ny)
+{
+	int x, y, pos, dt;
+	unpack(rec, x, y, pos, dt);
+	nx = x;
+	ny = y;
+	if (MODE != 0)
+	{
+		if (MODE == 2)
+		{
+			live = live && x >= 0 && x < c.image_w && y >= 0 && y < c.image_h;
+			const size_t at = live ? 2 * (static_cast<size_t>(y) * c.image_w + x) : 0;
+			const float2 f = *reinterpret_cast<const float2*>(field + at);
+			m0 = static_cast<double>(f.x);
+			m1 = static_cast<double>(f.y);
+		}
+		const double dtw = static_cast<double>(dt + dtWin);
+		const double fx = static_cast<double>(x) + dtw * c.scale * m0;
+		const double fy = static_cast<double>(y) + dtw * c.scale * m1;
+		live = live && convertible(fx) && convertible(fy);
+		nx = static_cast<int>(round(live ? fx : 0.0));
+		ny = static_cast<int>(round(live ? fy : 0.0));
+	}
+	return live && nx >= 0 && nx < c.image_w && ny >= 0 && ny < c.image_h;
+}
+
+// The flow of the patch a stray event (outside the sensor) is attributed to in the final
+// loop (:436-441, index clamped at 0: negative indices are undefined there).
+__device__ __forceinline__ void stray_flow(uint64_t rec, const double* __restrict__ windowFlows,
+										   const EvalConsts& c, double& m0, double& m1)
+{
+	int x, y, pos, dt;
+	unpack(rec, x, y, pos, dt);
+	const int px = max(min(x / c.patch_w, c.npx - 1), 0);
+	const int py = max(min(y / c.patch_h, c.npy - 1), 0);
+	m0 = windowFlows[2 * (py * c.npx + px)];
+	m1 = windowFlows[2 * (py * c.npx + px) + 1];
+}
+
 // LDS-privatised count image: workgroup = (row band, window).  The band's counters
 // live in LDS (16-bit counters packed two per dword when the window has < 65536
 // events, else 32-bit); the workgroup streams ALL events of its window once
@@ -1140,10 +1187,10 @@ __global__ void k_count_scatter(const uint64_t* __restrict__ events, const Unit*
 // those that land in its band with ds_add_u32, and writes the finished f64 rows
 // with plain coalesced stores.  HBM traffic = events once + image once: no global
 // atomics, no int32 intermediate image.  Bit-exact (integer adds commute).
-template <bool U16>
+template <bool U16, int MODE>
 __global__ void __launch_bounds__(1024) k_count_window_lds(
 	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
-	int mode, const void* __restrict__ aux, int rowsPerBand, int nWindows, double* __restrict__ image,
+	const void* __restrict__ aux, int rowsPerBand, int nWindows, double* __restrict__ image,
 	EvalConsts c)
 {
 	extern __shared__ unsigned int cnt[];
@@ -1167,100 +1214,77 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 	}
 	__syncthreads();
 	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
-	const uint32_t evBegin = wu[0].ev_off;
-	const uint32_t evEnd = wu[unitsPerWindow - 1].ev_off + wu[unitsPerWindow - 1].n_ev;
 	const int P = c.npx * c.npy;
 	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
-	const double* flows = static_cast<const double*>(aux);
-	int ui = 0;
-	uint32_t uEnd = wu[0].ev_off + wu[0].n_ev;
-	double m0 = 0.0, m1 = 0.0;
-	int dtWin = wu[0].dt_win;
-	bool stray = (wu[0].flags & kUnitStray) != 0;
-	if (mode == 1 && !stray)
-	{
-		m0 = flows[2 * wu[0].flow_idx];
-		m1 = flows[2 * wu[0].flow_idx + 1];
-	}
+	const double* windowFlows = static_cast<const double*>(aux) + (MODE == 1 ? 2 * static_cast<size_t>(w) * P : 0);
+	const float* windowField = static_cast<const float*>(aux) + (MODE == 2 ? 2 * static_cast<size_t>(w) * imgSize : 0);
 	// kInFlight independent 8-byte loads per lane are issued before the first is
 	// consumed: ~64 KiB in flight per CU, enough to cover HBM latency (Little's law).
 	constexpr int kInFlight = 8;
-	for (uint32_t eb = evBegin + threadIdx.x; eb < evEnd; eb += kInFlight * blockDim.x)
+	// pass 0: the patch units (one flow per unit); pass 1: the stray unit (flow per event)
+	for (int pass = 0; pass < 2; ++pass)
 	{
-		uint64_t recs[kInFlight];
+		int ui = pass == 0 ? 0 : P;
+		const int uLast = pass == 0 ? P - 1 : P;
+		const uint32_t evBegin = wu[ui].ev_off;
+		const uint32_t evEnd = wu[uLast].ev_off + wu[uLast].n_ev;
+		uint32_t uEnd = wu[ui].ev_off + wu[ui].n_ev;
+		int dtWin = wu[ui].dt_win;
+		double m0 = 0.0, m1 = 0.0;
+		if (MODE == 1 && pass == 0)
+		{
+			m0 = windowFlows[2 * ui];
+			m1 = windowFlows[2 * ui + 1];
+		}
+		for (uint32_t eb = evBegin + threadIdx.x; eb < evEnd; eb += kInFlight * blockDim.x)
+		{
+			uint64_t recs[kInFlight];
 #pragma unroll
-		for (int k = 0; k < kInFlight; ++k)
-		{
-			const uint32_t ek = eb + k * blockDim.x;
-			recs[k] = (ek < evEnd) ? events[ek] : 0ull;
-		}
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const uint32_t ek = eb + k * blockDim.x;
+				recs[k] = (ek < evEnd) ? events[ek] : 0ull;
+			}
 #pragma unroll
-		for (int k = 0; k < kInFlight; ++k)
-		{
-		const uint32_t e = eb + k * blockDim.x;
-		if (e >= evEnd)
-		{
-			break;
-		}
-		while (e >= uEnd)  // events are stored unit by unit: advance to the owning unit
-		{
-			++ui;
-			uEnd = wu[ui].ev_off + wu[ui].n_ev;
-			dtWin = wu[ui].dt_win;
-			stray = (wu[ui].flags & kUnitStray) != 0;
-			if (mode == 1 && !stray)
+			for (int k = 0; k < kInFlight; ++k)
 			{
-				m0 = flows[2 * wu[ui].flow_idx];
-				m1 = flows[2 * wu[ui].flow_idx + 1];
-			}
-		}
-		int x, y, pos, dt;
-		unpack(recs[k], x, y, pos, dt);
-		int nx = x, ny = y;
-		if (mode != 0)
-		{
-			if (mode == 1 && stray)
-			{
-				const int px = max(min(x / c.patch_w, c.npx - 1), 0);
-				const int py = max(min(y / c.patch_h, c.npy - 1), 0);
-				m0 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px)];
-				m1 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px) + 1];
-			}
-			if (mode == 2)
-			{
-				if (x < 0 || x >= W || y < 0 || y >= c.image_h)
+				const uint32_t e = eb + k * blockDim.x;
+				const bool live = e < evEnd;
+				if (MODE != 0 && live && e >= uEnd)  // events are stored unit by unit: advance
 				{
-					continue;
+					do
+					{
+						++ui;
+						uEnd = wu[ui].ev_off + wu[ui].n_ev;
+					} while (e >= uEnd);
+					dtWin = wu[ui].dt_win;
+					if (MODE == 1)
+					{
+						m0 = windowFlows[2 * ui];
+						m1 = windowFlows[2 * ui + 1];
+					}
 				}
-				const float* field = static_cast<const float*>(aux) +
-									 2 * (static_cast<size_t>(w) * imgSize + static_cast<size_t>(y) * W + x);
-				m0 = static_cast<double>(field[0]);
-				m1 = static_cast<double>(field[1]);
-			}
-			const double dtw = static_cast<double>(dt + dtWin);
-			const double fx = static_cast<double>(x) + dtw * c.scale * m0;
-			const double fy = static_cast<double>(y) + dtw * c.scale * m1;
-			if (!convertible(fx) || !convertible(fy))
-			{
-				continue;
-			}
-			nx = static_cast<int>(round(fx));
-			ny = static_cast<int>(round(fy));
-		}
-		const int ry = ny - row0;
-		if (nx >= 0 && nx < W && ry >= 0 && ry < rows)
-		{
-			const int p = ry * W + nx;
-			if (U16)
-			{
-				atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
-			}
-			else
-			{
-				atomicAdd(&cnt[p], 1u);
+				if (MODE == 1 && pass == 1)
+				{
+					stray_flow(recs[k], windowFlows, c, m0, m1);
+				}
+				int nx, ny;
+				const bool hit = count_target<MODE>(recs[k], live, dtWin, m0, m1, windowField, c, nx, ny);
+				const int ry = ny - row0;
+				if (hit && ry >= 0 && ry < rows)
+				{
+					const int p = ry * W + nx;
+					if (U16)
+					{
+						atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
+					}
+					else
+					{
+						atomicAdd(&cnt[p], 1u);
+					}
+				}
 			}
 		}
-		}  // k
 	}
 	__syncthreads();
 	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W;
@@ -1297,10 +1321,10 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 // k_count_overflow adds with f64 atomics after every band has stored its rows.  The stray
 // unit of the window (events outside the sensor) is streamed by band 0.  HBM traffic = events
 // once + image once, for any flow; integer adds commute => bit-exact.
-template <bool U16>
+template <bool U16, int MODE>
 __global__ void __launch_bounds__(512) k_count_bands(
 	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
-	int mode, const void* __restrict__ aux, int patchRowsPerBand, int nRegular, double* __restrict__ image,
+	const void* __restrict__ aux, int patchRowsPerBand, int nRegular, double* __restrict__ image,
 	unsigned long long* __restrict__ ovf /* [0] = count, then entries */, EvalConsts c)
 {
 	extern __shared__ unsigned int cnt[];
@@ -1342,7 +1366,8 @@ __global__ void __launch_bounds__(512) k_count_bands(
 	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
 	const int P = c.npx * c.npy;
 	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
-	const double* flows = static_cast<const double*>(aux);
+	const double* windowFlows = static_cast<const double*>(aux) + (MODE == 1 ? 2 * static_cast<size_t>(w) * P : 0);
+	const float* windowField = static_cast<const float*>(aux) + (MODE == 2 ? 2 * static_cast<size_t>(w) * imgSize : 0);
 	constexpr int kInFlight = 8;
 	// pass 0: the band's own patch units; pass 1 (band 0 only): the stray unit
 	for (int pass = 0; pass < (band == 0 ? 2 : 1); ++pass)
@@ -1355,10 +1380,10 @@ __global__ void __launch_bounds__(512) k_count_bands(
 		double m0 = 0.0, m1 = 0.0;
 		int dtWin = wu[ui].dt_win;
 		const bool stray = pass == 1;
-		if (mode == 1 && !stray)
+		if (MODE == 1 && !stray)
 		{
-			m0 = flows[2 * wu[ui].flow_idx];
-			m1 = flows[2 * wu[ui].flow_idx + 1];
+			m0 = windowFlows[2 * ui];
+			m1 = windowFlows[2 * ui + 1];
 		}
 		for (uint32_t eb = evBegin + threadIdx.x; eb < evEnd; eb += kInFlight * blockDim.x)
 		{
@@ -1375,55 +1400,27 @@ __global__ void __launch_bounds__(512) k_count_bands(
 				const uint32_t e = eb + k * blockDim.x;
 				// every lane of the wave walks the same k: the overflow append below is one
 				// atomic per wave (ballot + prefix count), so the tail lanes stay in the loop
-				bool live = e < evEnd;
-				if (live)
+				const bool inRange = e < evEnd;
+				if (MODE != 0 && inRange && e >= uEnd)
 				{
-					while (e >= uEnd)
+					do
 					{
 						++ui;
 						uEnd = wu[ui].ev_off + wu[ui].n_ev;
-						dtWin = wu[ui].dt_win;
-						if (mode == 1 && !stray)
-						{
-							m0 = flows[2 * wu[ui].flow_idx];
-							m1 = flows[2 * wu[ui].flow_idx + 1];
-						}
+					} while (e >= uEnd);
+					dtWin = wu[ui].dt_win;
+					if (MODE == 1)
+					{
+						m0 = windowFlows[2 * ui];
+						m1 = windowFlows[2 * ui + 1];
 					}
 				}
-				int x, y, pos, dt;
-				unpack(recs[k], x, y, pos, dt);
-				int nx = x, ny = y;
-				if (live && mode != 0)
+				if (MODE == 1 && stray)
 				{
-					if (mode == 1 && stray)
-					{
-						const int px = max(min(x / c.patch_w, c.npx - 1), 0);
-						const int py = max(min(y / c.patch_h, c.npy - 1), 0);
-						m0 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px)];
-						m1 = flows[2 * (static_cast<size_t>(w) * P + py * c.npx + px) + 1];
-					}
-					if (mode == 2)
-					{
-						live = x >= 0 && x < W && y >= 0 && y < c.image_h;
-						if (live)
-						{
-							const float* field = static_cast<const float*>(aux) +
-												 2 * (static_cast<size_t>(w) * imgSize + static_cast<size_t>(y) * W + x);
-							m0 = static_cast<double>(field[0]);
-							m1 = static_cast<double>(field[1]);
-						}
-					}
-					const double dtw = static_cast<double>(dt + dtWin);
-					const double fx = static_cast<double>(x) + dtw * c.scale * m0;
-					const double fy = static_cast<double>(y) + dtw * c.scale * m1;
-					live = live && convertible(fx) && convertible(fy);
-					if (live)
-					{
-						nx = static_cast<int>(round(fx));
-						ny = static_cast<int>(round(fy));
-					}
+					stray_flow(recs[k], windowFlows, c, m0, m1);
 				}
-				live = live && nx >= 0 && nx < W && ny >= 0 && ny < c.image_h;
+				int nx, ny;
+				const bool live = count_target<MODE>(recs[k], inRange, dtWin, m0, m1, windowField, c, nx, ny);
 				const int ry = ny - row0;
 				const bool inBand = live && ry >= 0 && ry < rows;
 				if (inBand)
@@ -1440,7 +1437,7 @@ __global__ void __launch_bounds__(512) k_count_bands(
 				}
 				// (a stray event is streamed by this workgroup only; an own event that lands in
 				// another sub-band of the same patch row is counted there)
-				const bool spill = live && !inBand &&
+				const bool spill = MODE != 0 && live && !inBand &&
 								   (stray || (reportsOutside && (ny < regionRow0 || ny >= regionRow1)));
 				const unsigned long long spillMask = __ballot(spill);
 				if (spillMask != 0ull)
@@ -1929,7 +1926,12 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		const bool want = L.impl == 1 || (L.impl < 0 && L.mode != 0 && bands <= 4 && L.n_windows * bands >= 64);
 		if (want && rowsPerBand > 0 && L.n_units_total > 0)
 		{
-			auto kern = u16 ? k_count_window_lds<true> : k_count_window_lds<false>;
+			auto kern = u16 ? (L.mode == 0	 ? k_count_window_lds<true, 0>
+							   : L.mode == 1 ? k_count_window_lds<true, 1>
+											 : k_count_window_lds<true, 2>)
+							: (L.mode == 0	 ? k_count_window_lds<false, 0>
+							   : L.mode == 1 ? k_count_window_lds<false, 1>
+											 : k_count_window_lds<false, 2>);
 			const size_t lds = (static_cast<size_t>(rowsPerBand) * L.c.image_w * (u16 ? 2 : 4) + 3) & ~size_t(3);
 			if (allow_big_lds(kern, lds))
 			{
@@ -1937,7 +1939,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			}
 			const int groups = (L.n_windows + 7) / 8;  // 8 windows (one per XCD) x bands slots each
 			hipLaunchKernelGGL(kern, dim3(groups * bands * 8), dim3(1024), lds, s, L.d_events, L.d_units,
-							   L.units_per_window, L.mode, L.d_aux, rowsPerBand, L.n_windows, L.d_image, L.c);
+							   L.units_per_window, L.d_aux, rowsPerBand, L.n_windows, L.d_image, L.c);
 			return check_launch();
 		}
 	}
@@ -1953,7 +1955,12 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		const int prb = std::max(1, static_cast<int>(ldsBytes / rowBytes) / L.c.patch_h);
 		const int bandRows = prb * L.c.patch_h;
 		const size_t lds = (static_cast<size_t>(bandRows) * rowBytes + 3) & ~size_t(3);
-		auto kern = u16 ? k_count_bands<true> : k_count_bands<false>;
+		auto kern = u16 ? (L.mode == 0	 ? k_count_bands<true, 0>
+						   : L.mode == 1 ? k_count_bands<true, 1>
+										 : k_count_bands<true, 2>)
+						: (L.mode == 0	 ? k_count_bands<false, 0>
+						   : L.mode == 1 ? k_count_bands<false, 1>
+										 : k_count_bands<false, 2>);
 		if (lds <= 160 * 1024 - 512 && allow_big_lds(kern, lds) == 0)
 		{
 			const int nRegular = (L.c.npy - 1 + prb - 1) / prb;
@@ -1964,7 +1971,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 				return -2;
 			}
 			hipLaunchKernelGGL(kern, dim3(nRegular + nSub, L.n_windows), dim3(512), lds, s, L.d_events, L.d_units,
-							   L.units_per_window, L.mode, L.d_aux, prb, nRegular, L.d_image, L.d_overflow, L.c);
+							   L.units_per_window, L.d_aux, prb, nRegular, L.d_image, L.d_overflow, L.c);
 			if (L.mode != 0)
 			{
 				hipLaunchKernelGGL(k_count_overflow, dim3(512), dim3(256), 0, s, L.d_overflow, L.d_image);
