@@ -13,7 +13,9 @@
  *   implementation/feature_tracker/src/feature_detector.cpp:243-482
  *   implementation/feature_tracker/src/patch.cpp:65-130
  *   tools/dataset_reader/src/davis240c_reader.cpp:60-92
- * Every function cites the lines it follows in oracle.cpp.
+ *   implementation/feature_tracker/include/feature_tracker/optimizer_cost.h,
+ *   implementation/feature_tracker/src/optimizer.cpp:62-119 (optimizer_oracle.cpp)
+ * Every function cites the lines it follows in oracle.cpp / optimizer_oracle.cpp.
  *
  * PARITY PINNING STATUS
  *   - The reference cannot be built in this image: it needs Ceres, Eigen 3.3.7, OpenCV,
@@ -31,6 +33,9 @@
  *     absent here; oracle.cpp restates its published Levenberg-Marquardt trust-region
  *     algorithm (docs "Solving Non-linear Least Squares", TrustRegionMinimizer /
  *     LevenbergMarquardtStrategy / TrustRegionStepEvaluator, v2.0 defaults).
+ *   - Tracker objective (optimizer_oracle.cpp): PARITY UNPINNED.  Ceres' bicubic interpolator
+ *     and Sophus' SE2 are restated from their published algorithms; no reference test
+ *     exercises Optimizer / OptimizerCostFunctor.
  */
 #ifndef EBO_ORACLE_H
 #define EBO_ORACLE_H
@@ -188,6 +193,32 @@ int orc_init_motion_field(int w, int h, double scale, int use_average, int n_pat
 int orc_interpolate_motion_field(int w, int h, int use_l1, float* field, int n_fixed,
 								 const int32_t* fixed_xy, const orc_solver_opts* opts,
 								 orc_summary* sum);
+
+/* ---- per-feature tracker objective (optimizer_oracle.cpp) ----------------
+ * tracker::OptimizerCostFunctor::operator() (optimizer_cost.h:30-96) as
+ * ceres::AutoDiffCostFunction<.., DYNAMIC, 4, 1>::Evaluate runs it: residuals [n], and when
+ * jac_pose / jac_flow are given the Jet<double,5> derivatives jac_pose [n][4] (w.r.t. the
+ * Sophus::SE2d storage [cos, sin, tx, ty]) and jac_flow [n]; both NULL = the double path
+ * (whose quotient rounds differently from the Jet path, as in the reference).
+ * grad: Optimizer::setGrad's grid, [img_h][img_w][2] = {gradX, gradY}; (rx, ry, rw, rh): the
+ * patch cv::Rect2d, n = int(rw) * int(rh); nabla: normalizedIntegratedNabla [int(rh)][int(rw)]. */
+int orc_optimizer_cost(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+					   const double* nabla, const double* pose, double flow_dir, double* residuals,
+					   double* jac_pose, double* jac_flow);
+/* Ceres defaults with optimizer.cpp:103-112 applied (10 iterations, non-monotonic). */
+void orc_optimizer_default_solver(orc_solver_opts* o);
+/* The ceres::Solve of Optimizer::optimize (optimizer.cpp:83-119): SE2 block with
+ * LocalParameterizationSE2 + scalar flow direction, one residual block with HuberLoss(huber_a),
+ * DENSE_QR.  pose [4], flow_dir in/out (lowest-cost point visited). */
+int orc_optimizer_solve(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+						const double* nabla, double huber_a, const orc_solver_opts* opts, double* pose,
+						double* flow_dir, orc_summary* summary);
+/* LocalParameterizationSE2::Plus: out = pose * exp(delta3), delta3 = (ux, uy, theta). */
+int orc_se2_plus(const double* pose, const double* delta3, double* out);
+/* Patch::updatePatchRect (patch.cpp:49-63): rect [4] from warp [4] and the initial centre. */
+int orc_patch_update_rect(const double* warp, double init_x, double init_y, double rw, double rh, double* rect);
+/* Patch::getNormalizedIntegratedNabla (patch.cpp:156-159). */
+int orc_normalize_nabla(const double* nabla, int n, double* out);
 
 /* Patch::integrateEvents (patch.cpp:65-85). ev in deque order (front = newest).
  * nabla [int(rh)][int(rw)]. */

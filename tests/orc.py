@@ -328,3 +328,68 @@ def interpolate_motion_field(field, fixed, use_l1=False, opts=None):
         int(w), int(h), int(bool(use_l1)), out.ctypes.data_as(C.c_void_p), len(fx),
         fx.ctypes.data_as(C.c_void_p), C.byref(opts) if opts is not None else None, C.byref(s))
     return out, s, rc
+
+
+# ---- per-feature tracker objective (optimizer_oracle.cpp) -------------------------------
+def optimizer_cost(grad, rect, nabla, pose, flow_dir, want_jac=True):
+    """OptimizerCostFunctor::operator().  grad [H][W][2], rect (x, y, w, h) doubles,
+    nabla [h][w].  Returns (residuals [n], jac_pose [n][4] | None, jac_flow [n] | None)."""
+    grad = np.ascontiguousarray(grad, dtype=np.float64)
+    nabla = np.ascontiguousarray(nabla, dtype=np.float64)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    h, w = grad.shape[:2]
+    n = int(rect[2]) * int(rect[3])
+    res = np.zeros(n)
+    jp = np.zeros((n, 4)) if want_jac else None
+    jf = np.zeros(n) if want_jac else None
+    rc = lib().orc_optimizer_cost(
+        _dp(grad), w, h, C.c_double(rect[0]), C.c_double(rect[1]), C.c_double(rect[2]), C.c_double(rect[3]),
+        _dp(nabla), _dp(pose), C.c_double(flow_dir), _dp(res), _dp(jp) if want_jac else None,
+        _dp(jf) if want_jac else None)
+    assert rc == 0
+    return res, jp, jf
+
+
+def optimizer_default_solver(**kw):
+    o = SolverOpts()
+    lib().orc_optimizer_default_solver(C.byref(o))
+    for key, val in kw.items():
+        setattr(o, key, val)
+    return o
+
+
+def optimizer_solve(grad, rect, nabla, pose, flow_dir, huber=0.3, opts=None):
+    grad = np.ascontiguousarray(grad, dtype=np.float64)
+    nabla = np.ascontiguousarray(nabla, dtype=np.float64)
+    p = np.ascontiguousarray(pose, dtype=np.float64).copy()
+    fd = C.c_double(flow_dir)
+    h, w = grad.shape[:2]
+    s = Summary()
+    rc = lib().orc_optimizer_solve(
+        _dp(grad), w, h, C.c_double(rect[0]), C.c_double(rect[1]), C.c_double(rect[2]), C.c_double(rect[3]),
+        _dp(nabla), C.c_double(huber), C.byref(opts) if opts is not None else None, _dp(p), C.byref(fd),
+        C.byref(s))
+    assert rc == 0
+    return p, fd.value, s
+
+
+def se2_plus(pose, delta3):
+    out = np.zeros(4)
+    assert lib().orc_se2_plus(_dp(np.ascontiguousarray(pose, dtype=np.float64)),
+                              _dp(np.ascontiguousarray(delta3, dtype=np.float64)), _dp(out)) == 0
+    return out
+
+
+def patch_update_rect(warp, init_xy, rw, rh):
+    out = np.zeros(4)
+    assert lib().orc_patch_update_rect(_dp(np.ascontiguousarray(warp, dtype=np.float64)),
+                                       C.c_double(init_xy[0]), C.c_double(init_xy[1]),
+                                       C.c_double(rw), C.c_double(rh), _dp(out)) == 0
+    return out
+
+
+def normalize_nabla(nabla):
+    a = np.ascontiguousarray(nabla, dtype=np.float64)
+    out = np.zeros_like(a)
+    assert lib().orc_normalize_nabla(_dp(a), a.size, _dp(out)) == 0
+    return out

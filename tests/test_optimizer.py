@@ -1,0 +1,163 @@
+"""Per-feature tracker objective: tracker::OptimizerCostFunctor
+(optimizer_cost.h:15-96) and the Ceres problem of Optimizer::optimize (optimizer.cpp:62-119).
+
+No test of the reference exercises this code and Ceres / Sophus are absent, so the oracle is
+PARITY UNPINNED; the CPU tests below check it against independent restatements of the
+published pieces (numpy Catmull-Rom bicubic, SE2 group identities, central differences of the
+oracle's own double-precision path).  The GPU tests compare the device path with the oracle.
+"""
+import numpy as np
+import pytest
+
+
+def make_scene(w=96, h=72, seed=0):
+    """A smooth synthetic image and its gradient grid [h][w][2] = (d/dx, d/dy)."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w))
+    for _ in range(6):
+        cx, cy = rng.uniform(10, w - 10), rng.uniform(10, h - 10)
+        s = rng.uniform(4, 9)
+        img += rng.uniform(-1, 1) * np.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * s * s))
+    gx = np.zeros_like(img)
+    gy = np.zeros_like(img)
+    gx[:, 1:-1] = 0.5 * (img[:, 2:] - img[:, :-2])
+    gy[1:-1, :] = 0.5 * (img[2:, :] - img[:-2, :])
+    return np.stack([gx, gy], axis=-1)
+
+
+def pose_of(theta, tx, ty):
+    return np.array([np.cos(theta), np.sin(theta), tx, ty])
+
+
+def catmull_rom(p0, p1, p2, p3, x):
+    a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3)
+    b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3)
+    c = 0.5 * (-p0 + p2)
+    return p1 + x * (c + x * (b + x * a))
+
+
+def bicubic_np(grid, r, c):
+    h, w = grid.shape[:2]
+    row, col = int(np.floor(r)), int(np.floor(c))
+    rows = []
+    for k in range(-1, 3):
+        ri = min(max(row + k, 0), h - 1)
+        p = [grid[ri, min(max(col + j, 0), w - 1)] for j in range(-1, 3)]
+        rows.append(catmull_rom(p[0], p[1], p[2], p[3], c - col))
+    return catmull_rom(rows[0], rows[1], rows[2], rows[3], r - row)
+
+
+def functor_np(grad, rect, nabla, pose, flow_dir):
+    """optimizer_cost.h:30-96 in numpy (double path)."""
+    h, w = grad.shape[:2]
+    pw, ph = int(rect[2]), int(rect[3])
+    vx, vy = np.cos(flow_dir), np.sin(flow_dir)
+    res = np.zeros(pw * ph)
+    norm = 1e-5
+    for y in range(ph):
+        for x in range(pw):
+            X, Y = x + rect[0], y + rect[1]
+            wx = pose[0] * X + (-pose[1]) * Y + pose[2]
+            wy = pose[1] * X + pose[0] * Y + pose[3]
+            if wx >= w or wy >= h or wx < 0 or wy < 0:
+                continue
+            g = bicubic_np(grad, wy, wx)
+            res[x + pw * y] = g[0] * vx + g[1] * vy
+            norm += res[x + pw * y] ** 2
+    return res / np.sqrt(norm) + np.asarray(nabla).ravel()
+
+
+def test_functor_matches_numpy_restatement(orc):
+    grad = make_scene()
+    rect = (30.25, 20.5, 25.0, 25.0)
+    rng = np.random.default_rng(1)
+    nabla = orc.normalize_nabla(rng.integers(-3, 4, (25, 25)).astype(np.float64))
+    for pose, fd in ((pose_of(0.0, 0.0, 0.0), 0.3), (pose_of(0.07, 1.3, -2.1), 2.0),
+                     (pose_of(-0.4, 30.0, 5.0), -1.0), (pose_of(0.1, -28.0, -18.0), 0.5)):
+        res, _, _ = orc.optimizer_cost(grad, rect, nabla, pose, fd, want_jac=False)
+        ref = functor_np(grad, rect, nabla, pose, fd)
+        assert np.abs(res - ref).max() < 1e-13
+    # a patch warped completely outside the image: every predicted value is 0
+    res, jp, jf = orc.optimizer_cost(grad, rect, nabla, pose_of(0.0, 500.0, 0.0), 0.3)
+    assert np.array_equal(res, nabla.ravel()) and not jp.any() and not jf.any()
+
+
+def test_jet_jacobian_matches_central_differences(orc):
+    grad = make_scene(seed=3)
+    rect = (40.0, 25.0, 25.0, 25.0)
+    nabla = orc.normalize_nabla(np.random.default_rng(2).integers(-2, 3, (25, 25)).astype(np.float64))
+    pose, fd = pose_of(0.05, 0.8, -0.6), 0.9
+    res, jp, jf = orc.optimizer_cost(grad, rect, nabla, pose, fd)
+    res_d, _, _ = orc.optimizer_cost(grad, rect, nabla, pose, fd, want_jac=False)
+    assert np.abs(res - res_d).max() < 1e-14  # Jet and double quotients round differently
+    eps = 1e-6
+    for k in range(4):  # w.r.t. the raw storage [cos, sin, tx, ty], as Jet<double,5> seeds it
+        d = np.zeros(4)
+        d[k] = eps
+        hi, _, _ = orc.optimizer_cost(grad, rect, nabla, pose + d, fd, want_jac=False)
+        lo, _, _ = orc.optimizer_cost(grad, rect, nabla, pose - d, fd, want_jac=False)
+        assert np.abs((hi - lo) / (2 * eps) - jp[:, k]).max() < 2e-6
+    hi, _, _ = orc.optimizer_cost(grad, rect, nabla, pose, fd + eps, want_jac=False)
+    lo, _, _ = orc.optimizer_cost(grad, rect, nabla, pose, fd - eps, want_jac=False)
+    assert np.abs((hi - lo) / (2 * eps) - jf).max() < 2e-6
+
+
+def test_se2_plus_and_patch_rect(orc):
+    T = pose_of(0.3, 4.0, -2.0)
+    # exp of a pure rotation / pure translation; group law against 3x3 matrices
+    def mat(p):
+        return np.array([[p[0], -p[1], p[2]], [p[1], p[0], p[3]], [0, 0, 1.0]])
+    for d in ((0.5, -0.25, 0.0), (0.0, 0.0, 0.4), (1.5, 0.7, -0.9), (0.3, 0.1, 1e-12)):
+        out = orc.se2_plus(T, d)
+        th = d[2]
+        if abs(th) < 1e-10:
+            V = np.array([[1.0, -0.5 * th], [0.5 * th, 1.0]])  # the series Sophus uses below 1e-10
+        else:
+            V = np.array([[np.sin(th) / th, -(1 - np.cos(th)) / th], [(1 - np.cos(th)) / th, np.sin(th) / th]])
+        t = V @ np.array(d[:2])
+        E = np.array([[np.cos(th), -np.sin(th), t[0]], [np.sin(th), np.cos(th), t[1]], [0, 0, 1.0]])
+        assert np.abs(mat(out) - mat(T) @ E).max() < 1e-14
+        assert abs(out[0] ** 2 + out[1] ** 2 - 1.0) < 1e-15
+    # Patch::updatePatchRect: centre = warp^-1 * initPoint, extent kept (patch.cpp:49-63)
+    rect = orc.patch_update_rect(T, (50.0, 40.0), 25.0, 25.0)
+    c = np.linalg.inv(mat(T)) @ np.array([50.0, 40.0, 1.0])
+    assert np.allclose(rect, [c[0] - 12, c[1] - 12, 25, 25], atol=1e-13)
+
+
+def make_problem(orc, seed, theta=0.04, t=(0.9, -0.7), flow=0.8, rect=(36.0, 24.0, 25.0, 25.0)):
+    """A patch whose 'integrated nabla' is minus the prediction at a known pose: the optimum."""
+    grad = make_scene(seed=seed)
+    true_pose = pose_of(theta, *t)
+    zero = np.zeros((int(rect[3]), int(rect[2])))
+    pred, _, _ = orc.optimizer_cost(grad, rect, zero, true_pose, flow, want_jac=False)
+    nabla = orc.normalize_nabla((-pred).reshape(zero.shape))
+    return grad, rect, nabla, true_pose, flow
+
+
+def test_solve_recovers_a_known_warp(orc):
+    grad, rect, nabla, true_pose, flow = make_problem(orc, 5)
+    opts = orc.optimizer_default_solver(max_num_iterations=30)
+    pose, fd, s = orc.optimizer_solve(grad, rect, nabla, pose_of(0.0, 0.0, 0.0), flow + 0.2, opts=opts)
+    assert s.termination == 0 and s.final_cost < 1e-6 * max(s.initial_cost, 1e-12) + 1e-9
+    assert np.abs(pose - true_pose).max() < 1e-3
+    assert abs(pose[0] ** 2 + pose[1] ** 2 - 1.0) < 1e-12  # stays on the group
+    # the reference's 10-iteration default: cost never increases, lowest-cost point returned
+    pose10, fd10, s10 = orc.optimizer_solve(grad, rect, nabla, pose_of(0.0, 0.0, 0.0), flow + 0.2)
+    assert s10.iterations <= 10 and s10.final_cost <= s10.initial_cost
+    res, _, _ = orc.optimizer_cost(grad, rect, nabla, pose10, fd10, want_jac=False)
+    sq = float(res @ res)
+    huber = sq if sq <= 0.09 else 2 * 0.3 * np.sqrt(sq) - 0.09
+    assert 0.5 * huber == pytest.approx(s10.final_cost, rel=1e-12)
+
+
+def test_solve_with_empty_patch_fails_cleanly(orc):
+    grad = make_scene(seed=6)
+    rect = (36.0, 24.0, 25.0, 25.0)
+    with np.errstate(all="ignore"):
+        nabla = orc.normalize_nabla(np.zeros((25, 25)))  # 0 * (1 / 0): NaN, as in the reference
+    assert np.isnan(nabla).all()
+    p0 = pose_of(0.1, 1.0, 2.0)
+    pose, fd, s = orc.optimizer_solve(grad, rect, nabla, p0, 0.5)
+    assert s.termination == 2 and s.iterations == 0
+    assert np.array_equal(pose, p0) and fd == 0.5
