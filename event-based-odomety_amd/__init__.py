@@ -163,6 +163,17 @@ def default_solver(**kw):
     return o
 
 
+def optimizer_default_solver(**kw):
+    """ceres::Solver::Options as Optimizer::optimize sets them (optimizer.cpp:103-112)."""
+    o = SolverOpts()
+    lib().ebo_optimizer_default_solver(C.byref(o))
+    for key, val in kw.items():
+        if not hasattr(o, key):
+            raise AttributeError(key)
+        setattr(o, key, val)
+    return o
+
+
 def shard_range(n_units, rank, world):
     b, e = C.c_int(), C.c_int()
     rc = lib().ebo_shard_range(int(n_units), int(rank), int(world), C.byref(b), C.byref(e))
@@ -396,6 +407,48 @@ class Context:
             self._h, int(bool(use_l1)), C.byref(opts) if opts is not None else None, _vp(field),
             C.byref(s), C.byref(cg)))
         return field, s, cg.value
+
+    # -- per-feature tracker objective (Optimizer / OptimizerCostFunctor) ------
+    def optimizer_set_grad(self, grad_x, grad_y):
+        gx = np.ascontiguousarray(grad_x, dtype=np.float64)
+        gy = np.ascontiguousarray(grad_y, dtype=np.float64)
+        assert gx.shape == gy.shape == (self.params.image_h, self.params.image_w)
+        self._check(lib().ebo_optimizer_set_grad(self._h, _dp(gx), _dp(gy)))
+
+    @staticmethod
+    def _opt_inputs(rects, nablas, poses, flow_dirs):
+        rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        nabla = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in nablas])
+                                     if len(nablas) else np.zeros(0))
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4).copy()
+        flow_dirs = np.ascontiguousarray(flow_dirs, dtype=np.float64).reshape(-1).copy()
+        sizes = [int(r[2]) * int(r[3]) for r in rects]
+        assert nabla.size == sum(sizes)
+        return rects, nabla, poses, flow_dirs, sizes
+
+    def optimizer_eval(self, rects, nablas, poses, flow_dirs, want_jac=True):
+        """OptimizerCostFunctor for n patches.  Returns lists (residuals, jac_pose, jac_flow)."""
+        rects, nabla, poses, flow_dirs, sizes = self._opt_inputs(rects, nablas, poses, flow_dirs)
+        total = sum(sizes)
+        res = np.zeros(total)
+        jp = np.zeros((total, 4)) if want_jac else None
+        jf = np.zeros(total) if want_jac else None
+        self._check(lib().ebo_optimizer_eval(
+            self._h, len(rects), _dp(rects), _dp(nabla), _dp(poses), _dp(flow_dirs), _dp(res),
+            _dp(jp) if want_jac else None, _dp(jf) if want_jac else None))
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        cut = lambda a: [a[offs[i]:offs[i + 1]] for i in range(len(sizes))]
+        return cut(res), (cut(jp) if want_jac else None), (cut(jf) if want_jac else None)
+
+    def optimizer_solve(self, rects, nablas, poses, flow_dirs, normalize=False, huber=0.3, opts=None):
+        """Optimizer::optimize's ceres::Solve for n patches.  Returns (poses, flow_dirs, summaries)."""
+        rects, nabla, poses, flow_dirs, sizes = self._opt_inputs(rects, nablas, poses, flow_dirs)
+        n = len(rects)
+        sums = (Summary * max(n, 1))()
+        self._check(lib().ebo_optimizer_solve(
+            self._h, n, _dp(rects), _dp(nabla), int(bool(normalize)), C.c_double(huber),
+            C.byref(opts) if opts is not None else None, _dp(poses), _dp(flow_dirs), sums))
+        return poses, flow_dirs, list(sums)[:n]
 
     # -- tracked-feature patches (Patch::integrate*) --------------------------
     def patch_integrate(self, ev, offsets, rects):

@@ -63,6 +63,10 @@ struct ebo_ctx
 	double* d_image = nullptr;
 	void* d_aux = nullptr;
 	size_t aux_cap = 0;
+	double2* d_opt_grid = nullptr;   // Optimizer::setGrad's interleaved gradient grid [H][W]
+	bool opt_grid_valid = false;
+	void* d_opt = nullptr;           // scratch of ebo_optimizer_eval / _solve
+	size_t opt_cap = 0;
 	unsigned long long* d_count_ovf = nullptr;  // k_count_bands' overflow list
 	size_t count_ovf_cap = 0;
 	int32_t* d_stats = nullptr;
@@ -614,6 +618,8 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 			if (c->d_count_ovf)
 			{
 				hipFree(c->d_count_ovf);
+	hipFree(c->d_opt_grid);
+	hipFree(c->d_opt);
 				c->d_count_ovf = nullptr;
 				c->count_ovf_cap = 0;
 			}
@@ -2234,6 +2240,326 @@ int ebo_interpolate_motion_field(ebo_ctx* c, int use_l1, const ebo_solver_opts* 
 		}
 	}
 	return st.termination == 2 ? c->fail(EBO_ERR_SOLVER, "field TV solve failed") : EBO_OK;
+}
+
+// ---- per-feature tracker objective ---------------------------------------
+void ebo_optimizer_default_solver(ebo_solver_opts* o)
+{
+	if (!o)
+	{
+		return;
+	}
+	ebo_default_solver(o);
+	o->max_num_iterations = 10;  // OptimizerParams::maxNumIterations
+	o->use_nonmonotonic = 1;     // optimizer.cpp:110
+	o->function_tolerance = 1e-6;
+	o->gradient_tolerance = 1e-10;
+	o->parameter_tolerance = 1e-8;
+	o->mode = EBO_SOLVE_INDEPENDENT;
+}
+
+int ebo_optimizer_set_grad(ebo_ctx* c, const double* grad_x, const double* grad_y)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!grad_x || !grad_y)
+	{
+		return c->fail(EBO_ERR_ARG, "null gradient image");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t n = static_cast<size_t>(c->prm.image_w) * c->prm.image_h;
+	int rc = EBO_OK;
+	if (!c->d_opt_grid)
+	{
+		rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_opt_grid), n * sizeof(double2)), "hipMalloc gradient grid");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	rc = ensure_aux(c, 2 * n * sizeof(double));
+	if (rc)
+	{
+		return rc;
+	}
+	double* stage = static_cast<double*>(c->d_aux);
+	hipError_t e = hipMemcpyAsync(stage, grad_x, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess)
+	{
+		e = hipMemcpyAsync(stage + n, grad_y, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	}
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D gradient images");
+	}
+	if (launch_optimizer_interleave(stage, stage + n, n, c->d_opt_grid, c->stream))
+	{
+		return c->hip(hipGetLastError(), "gradient grid launch");
+	}
+	rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	c->opt_grid_valid = rc == EBO_OK;
+	return rc;
+}
+
+namespace
+{
+struct OptBuffers
+{
+	OptPatch* patches;
+	double* nabla_in;
+	double* nabla;
+	double* x;
+	double* stats;
+	double* res;
+	double* jac_pose;
+	double* jac_flow;
+	size_t total;
+	int max_pixels;
+};
+
+// Validates the rects, uploads patches / nabla / parameters; normalize: nabla is the raw
+// integrated nabla and is normalised on the device (Patch::getNormalizedIntegratedNabla).
+int optimizer_stage(ebo_ctx* c, int n, const double* rects, const double* nabla, int normalize,
+					const double* poses, const double* flow_dirs, bool wantRes, bool wantJac, OptBuffers& B)
+{
+	if (!c->opt_grid_valid)
+	{
+		return c->fail(EBO_ERR_STATE, "ebo_optimizer_set_grad has not been called");
+	}
+	if (n < 0 || (n > 0 && (!rects || !nabla || !poses || !flow_dirs)))
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to the optimizer");
+	}
+	std::vector<OptPatch> hp(n);
+	size_t total = 0;
+	int maxPx = 1;
+	for (int i = 0; i < n; ++i)
+	{
+		const double w = rects[4 * i + 2], h = rects[4 * i + 3];
+		if (!(w >= 1.0) || !(h >= 1.0) || w > 4096.0 || h > 4096.0 || !std::isfinite(rects[4 * i]) ||
+			!std::isfinite(rects[4 * i + 1]))
+		{
+			return c->fail(EBO_ERR_ARG, "bad patch rect");
+		}
+		hp[i].rx = rects[4 * i];
+		hp[i].ry = rects[4 * i + 1];
+		hp[i].pw = static_cast<int>(w);
+		hp[i].ph = static_cast<int>(h);
+		hp[i].off = total;
+		const int px = hp[i].pw * hp[i].ph;
+		if (px > 3000)
+		{
+			return c->fail(EBO_ERR_UNSUPPORTED, "tracked patch larger than 3000 pixels");
+		}
+		maxPx = std::max(maxPx, px);
+		total += static_cast<size_t>(px);
+	}
+	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+	const size_t bPatch = al(static_cast<size_t>(n) * sizeof(OptPatch)), bVec = al(total * 8);
+	const size_t bX = al(static_cast<size_t>(n) * 5 * 8), bStats = al(static_cast<size_t>(n) * 8 * 8);
+	const size_t need = bPatch + 2 * bVec + bX + bStats + (wantRes ? bVec : 0) + (wantJac ? 5 * bVec : 0) + 256;
+	(void)hipSetDevice(c->prm.device);
+	if (need > c->opt_cap)
+	{
+		if (c->d_opt)
+		{
+			hipFree(c->d_opt);
+			c->d_opt = nullptr;
+			c->opt_cap = 0;
+		}
+		int rc = c->hip(hipMalloc(&c->d_opt, need), "hipMalloc optimizer scratch");
+		if (rc)
+		{
+			return rc;
+		}
+		c->opt_cap = need;
+	}
+	char* b = static_cast<char*>(c->d_opt);
+	B.patches = reinterpret_cast<OptPatch*>(b);
+	b += bPatch;
+	B.nabla_in = reinterpret_cast<double*>(b);
+	b += bVec;
+	B.nabla = reinterpret_cast<double*>(b);
+	b += bVec;
+	B.x = reinterpret_cast<double*>(b);
+	b += bX;
+	B.stats = reinterpret_cast<double*>(b);
+	b += bStats;
+	B.res = wantRes ? reinterpret_cast<double*>(b) : nullptr;
+	b += wantRes ? bVec : 0;
+	B.jac_pose = wantJac ? reinterpret_cast<double*>(b) : nullptr;
+	b += wantJac ? 4 * bVec : 0;
+	B.jac_flow = wantJac ? reinterpret_cast<double*>(b) : nullptr;
+	B.total = total;
+	B.max_pixels = maxPx;
+	if (n == 0)
+	{
+		return EBO_OK;
+	}
+	std::vector<double> hx(static_cast<size_t>(n) * 5);
+	for (int i = 0; i < n; ++i)
+	{
+		for (int k = 0; k < 4; ++k)
+		{
+			hx[5 * i + k] = poses[4 * i + k];
+		}
+		hx[5 * i + 4] = flow_dirs[i];
+	}
+	hipError_t e = hipMemcpyAsync(B.patches, hp.data(), static_cast<size_t>(n) * sizeof(OptPatch), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess)
+	{
+		e = hipMemcpyAsync(normalize ? B.nabla_in : B.nabla, nabla, total * 8, hipMemcpyHostToDevice, c->stream);
+	}
+	if (e == hipSuccess)
+	{
+		e = hipMemcpyAsync(B.x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice, c->stream);
+	}
+	if (e == hipSuccess)
+	{
+		e = hipStreamSynchronize(c->stream);  // hp / hx are locals
+	}
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D optimizer inputs");
+	}
+	if (normalize && launch_optimizer_normalize(B.patches, n, B.nabla_in, B.nabla, c->stream))
+	{
+		return c->hip(hipGetLastError(), "nabla normalisation launch");
+	}
+	return EBO_OK;
+}
+
+OptLaunch optimizer_launch(const ebo_ctx* c, int n, const OptBuffers& B)
+{
+	OptLaunch L;
+	std::memset(&L, 0, sizeof(L));
+	L.d_grid = c->d_opt_grid;
+	L.img_w = c->prm.image_w;
+	L.img_h = c->prm.image_h;
+	L.d_patches = B.patches;
+	L.n_patches = n;
+	L.max_pixels = B.max_pixels;
+	L.d_nabla = B.nabla;
+	L.d_x = B.x;
+	L.d_res = B.res;
+	L.d_jac_pose = B.jac_pose;
+	L.d_jac_flow = B.jac_flow;
+	L.d_stats = B.stats;
+	return L;
+}
+}  // namespace
+
+int ebo_optimizer_eval(ebo_ctx* c, int n, const double* rects, const double* nabla, const double* poses,
+					   const double* flow_dirs, double* residuals, double* jac_pose, double* jac_flow)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!residuals || ((jac_pose == nullptr) != (jac_flow == nullptr)))
+	{
+		return c->fail(EBO_ERR_ARG, "residuals are required; the two Jacobians come together");
+	}
+	OptBuffers B;
+	int rc = optimizer_stage(c, n, rects, nabla, 0, poses, flow_dirs, true, jac_pose != nullptr, B);
+	if (rc || n == 0)
+	{
+		return rc;
+	}
+	OptLaunch L = optimizer_launch(c, n, B);
+	if (launch_optimizer_eval(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "optimizer evaluation launch");
+	}
+	hipError_t e = hipMemcpyAsync(residuals, B.res, B.total * 8, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess && jac_pose)
+	{
+		e = hipMemcpyAsync(jac_pose, B.jac_pose, B.total * 4 * 8, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess && jac_flow)
+	{
+		e = hipMemcpyAsync(jac_flow, B.jac_flow, B.total * 8, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess)
+	{
+		e = hipStreamSynchronize(c->stream);
+	}
+	return c->hip(e, "D2H optimizer results");
+}
+
+int ebo_optimizer_solve(ebo_ctx* c, int n, const double* rects, const double* nabla, int normalize, double huber,
+						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	ebo_solver_opts o;
+	if (opts)
+	{
+		o = *opts;
+		o.mode = EBO_SOLVE_INDEPENDENT;
+		int rc = check_solver_opts(c, &o);
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	else
+	{
+		ebo_optimizer_default_solver(&o);
+	}
+	if (!(huber > 0.0))
+	{
+		return c->fail(EBO_ERR_ARG, "the Huber parameter must be positive");
+	}
+	OptBuffers B;
+	int rc = optimizer_stage(c, n, rects, nabla, normalize, poses, flow_dirs, false, false, B);
+	if (rc || n == 0)
+	{
+		return rc;
+	}
+	OptLaunch L = optimizer_launch(c, n, B);
+	L.huber = huber;
+	L.s = make_solve_consts(&o);
+	if (launch_optimizer_solve(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "optimizer solve launch");
+	}
+	std::vector<double> hx(static_cast<size_t>(n) * 5), hs(static_cast<size_t>(n) * 8);
+	hipError_t e = hipMemcpyAsync(hx.data(), B.x, hx.size() * 8, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess)
+	{
+		e = hipMemcpyAsync(hs.data(), B.stats, hs.size() * 8, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess)
+	{
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "D2H optimizer results");
+	}
+	for (int i = 0; i < n; ++i)
+	{
+		for (int k = 0; k < 4; ++k)
+		{
+			poses[4 * i + k] = hx[5 * i + k];
+		}
+		flow_dirs[i] = hx[5 * i + 4];
+		if (summaries)
+		{
+			summaries[i].iterations = static_cast<int32_t>(hs[8 * i + 0]);
+			summaries[i].num_evals_cost = static_cast<int32_t>(hs[8 * i + 1]);
+			summaries[i].num_evals_jac = static_cast<int32_t>(hs[8 * i + 2]);
+			summaries[i].termination = static_cast<int32_t>(hs[8 * i + 3]);
+			summaries[i].initial_cost = hs[8 * i + 4];
+			summaries[i].final_cost = hs[8 * i + 5];
+		}
+	}
+	return EBO_OK;
 }
 
 // DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one

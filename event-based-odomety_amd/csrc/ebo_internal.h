@@ -244,6 +244,34 @@ int launch_tvf_cg_iters(const TvfArgs& A, int first_iter, int iters, void* strea
 int launch_tvf_model(const TvfArgs& A, void* stream);
 int launch_tvf_store(const TvfArgs& A, const double2* X, float* d_field, void* stream);
 
+// The per-feature tracker objective (ebo_optimizer.inc): one tracked patch.
+struct OptPatch
+{
+	double rx, ry;           // patch_.tl()
+	int pw, ph;              // int(patch_.width), int(patch_.height)
+	unsigned long long off;  // first residual of this patch in the concatenated arrays
+};
+struct OptLaunch
+{
+	const double2* d_grid;   // [img_h][img_w] (gradX, gradY)
+	int img_w, img_h;
+	const OptPatch* d_patches;
+	int n_patches;
+	int max_pixels;          // max pw * ph over the patches (LDS sizing)
+	const double* d_nabla;   // normalizedIntegratedNabla, concatenated
+	double* d_x;             // [n][5] = pose (cos, sin, tx, ty), flow direction
+	double* d_res;           // eval: residuals, concatenated
+	double* d_jac_pose;      // eval: [..][4] or null
+	double* d_jac_flow;      // eval: [..] or null
+	double* d_stats;         // solve: [n][8]
+	double huber;
+	SolveConsts s;
+};
+int launch_optimizer_eval(const OptLaunch& L, void* stream);
+int launch_optimizer_solve(const OptLaunch& L, void* stream);
+int launch_optimizer_normalize(const OptPatch* d_patches, int n, const double* d_in, double* d_out, void* stream);
+int launch_optimizer_interleave(const double* d_gx, const double* d_gy, size_t n, double2* d_grid, void* stream);
+
 struct PatchIntLaunch
 {
 	const uint64_t* d_events;  // packed, dt = mid_time - t

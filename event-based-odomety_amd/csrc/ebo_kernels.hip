@@ -1583,6 +1583,7 @@ __global__ void k_patch_integrate(const uint64_t* __restrict__ events,
 #include "ebo_bucket.inc"
 #include "ebo_field.inc"
 #include "ebo_fieldtv.inc"
+#include "ebo_optimizer.inc"
 
 int check_launch()
 {
@@ -1797,6 +1798,65 @@ int launch_tvf_store(const TvfArgs& A, const double2* X, float* d_field, void* s
 	const unsigned blocks = static_cast<unsigned>((A.n + 255) / 256);
 	hipLaunchKernelGGL(k_tvf_store, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), A.n, X,
 					   reinterpret_cast<float2*>(d_field));
+	return check_launch();
+}
+
+namespace
+{
+size_t optimizer_lds_bytes(int maxPixels)
+{
+	return (128 + static_cast<size_t>(maxPixels) * 6) * sizeof(double);
+}
+}  // namespace
+
+int launch_optimizer_eval(const OptLaunch& L, void* stream)
+{
+	if (L.n_patches == 0)
+	{
+		return 0;
+	}
+	const size_t lds = optimizer_lds_bytes(L.max_pixels);
+	if (lds > 160 * 1024 - 512 || allow_big_lds(k_optimizer_eval, lds))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_optimizer_eval, dim3(L.n_patches), dim3(256), lds, static_cast<hipStream_t>(stream),
+					   L.d_grid, L.img_w, L.img_h, L.d_patches, L.d_nabla, L.d_x, L.d_res, L.d_jac_pose,
+					   L.d_jac_flow);
+	return check_launch();
+}
+
+int launch_optimizer_solve(const OptLaunch& L, void* stream)
+{
+	if (L.n_patches == 0)
+	{
+		return 0;
+	}
+	const size_t lds = optimizer_lds_bytes(L.max_pixels);
+	if (lds > 160 * 1024 - 512 || allow_big_lds(k_optimizer_solve, lds))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_optimizer_solve, dim3(L.n_patches), dim3(256), lds, static_cast<hipStream_t>(stream),
+					   L.d_grid, L.img_w, L.img_h, L.d_patches, L.d_nabla, L.d_x, L.d_stats, L.huber, L.s);
+	return check_launch();
+}
+
+int launch_optimizer_normalize(const OptPatch* d_patches, int n, const double* d_in, double* d_out, void* stream)
+{
+	if (n == 0)
+	{
+		return 0;
+	}
+	hipLaunchKernelGGL(k_optimizer_normalize, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), d_patches,
+					   d_in, d_out);
+	return check_launch();
+}
+
+int launch_optimizer_interleave(const double* d_gx, const double* d_gy, size_t n, double2* d_grid, void* stream)
+{
+	hipLaunchKernelGGL(k_optimizer_interleave, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+					   static_cast<hipStream_t>(stream), d_gx, d_gy, n, d_grid);
 	return check_launch();
 }
 

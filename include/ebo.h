@@ -235,6 +235,36 @@ int ebo_init_motion_field(ebo_ctx* ctx, int64_t timestamp, int use_average, int 
 int ebo_interpolate_motion_field(ebo_ctx* ctx, int use_l1, const ebo_solver_opts* opts, float* field_out,
 								 ebo_summary* summary, int32_t* cg_iterations);
 
+/* ---- per-feature tracker objective --------------------------------------
+ * tracker::Optimizer::setGrad (optimizer.cpp:15-31): the image-gradient grid the tracker samples
+ * with ceres::BiCubicInterpolator.  grad_x, grad_y: host [image_h][image_w] (CV_64F). */
+int ebo_optimizer_set_grad(ebo_ctx* ctx, const double* grad_x, const double* grad_y);
+/* ceres::Solver::Options as Optimizer::optimize sets them (optimizer.cpp:103-112;
+ * OptimizerParams::maxNumIterations = 10). */
+void ebo_optimizer_default_solver(ebo_solver_opts* o);
+/* tracker::OptimizerCostFunctor (optimizer_cost.h:15-96) behind
+ * ceres::AutoDiffCostFunction<OptimizerCostFunctor, ceres::DYNAMIC, 4, 1>::Evaluate
+ * (optimizer.cpp:89-97), for n tracked patches in one launch.  rects [n][4] = cv::Rect2d
+ * (x, y, width, height); patch i has m_i = int(width) * int(height) residuals, stored
+ * consecutively; nabla: Patch::getNormalizedIntegratedNabla per patch ([m_i], row-major);
+ * poses [n][4] = Sophus::SE2d::data() (cos, sin, tx, ty); flow_dirs [n].
+ * residuals [sum m_i]; jac_pose [sum m_i][4] and jac_flow [sum m_i] are the Jacobians Ceres asks
+ * for (row-major, w.r.t. the 4 stored SE2 parameters and the flow angle), both NULL = value only
+ * (the double path of the functor, whose quotient rounds differently from the Jet path, as in
+ * the reference).  Needs ebo_optimizer_set_grad (EBO_ERR_STATE). */
+int ebo_optimizer_eval(ebo_ctx* ctx, int n, const double* rects, const double* nabla, const double* poses,
+					   const double* flow_dirs, double* residuals, double* jac_pose, double* jac_flow);
+/* The ceres::Solve of tracker::Optimizer::optimize (optimizer.cpp:83-119) for n tracked patches
+ * in one launch: SE2 block with Sophus' LocalParameterizationSE2 + the flow angle, one residual
+ * block with ceres::HuberLoss(huber) (OptimizerParams::huberLoss = 0.3), trust-region LM with the
+ * options of :103-112 (opts == NULL; DENSE_QR there, a 4x4 Cholesky of the same normal equations
+ * here).  normalize != 0: nabla is Patch::getIntegratedNabla and is normalised on the device as
+ * Patch::getNormalizedIntegratedNabla does (patch.cpp:156-159; an all-zero patch gives NaN and
+ * termination 2, parameters unchanged).  poses, flow_dirs: in = Patch::getWarp / getFlow, out =
+ * the lowest-cost point visited.  summaries [n] may be NULL. */
+int ebo_optimizer_solve(ebo_ctx* ctx, int n, const double* rects, const double* nabla, int normalize, double huber,
+						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries);
+
 /* R2 in one call: set window, solve, final warped count image.
  * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */
 int ebo_compensate_events_contrast(ebo_ctx* ctx, const ebo_event* ev, size_t n,

@@ -670,7 +670,57 @@ void minimizeBlock(Block& blk, const orc_solver_opts& o, double* x, orc_summary*
 			A[static_cast<size_t>(m + c) * n + c] = lmDiag[c];
 		}
 		std::copy(f.begin(), f.end(), b.begin());
-		bool valid = qrSolve(A, m + n, n, b, step);
+		bool valid = true;
+		if (o.mode == 1)
+		{
+			// diagnostic only (tests/diag_optimizer.py): the same step from the normal equations
+			// (J'J + D'D) x = J'f by Gaussian elimination, to tell the conditioning of the
+			// problem from the linear solver used
+			double Hn[NT][NT + 1];
+			for (int a = 0; a < n; ++a)
+			{
+				for (int c = 0; c <= n; ++c)
+				{
+					Hn[a][c] = 0.0;
+				}
+			}
+			for (int r = 0; r < m + n; ++r)
+			{
+				for (int a = 0; a < n; ++a)
+				{
+					for (int c = 0; c < n; ++c)
+					{
+						Hn[a][c] += A[static_cast<size_t>(r) * n + a] * A[static_cast<size_t>(r) * n + c];
+					}
+					Hn[a][n] += A[static_cast<size_t>(r) * n + a] * b[r];
+				}
+			}
+			for (int k = 0; k < n && valid; ++k)
+			{
+				valid = Hn[k][k] > 0.0;
+				for (int r = k + 1; r < n && valid; ++r)
+				{
+					const double fct = Hn[r][k] / Hn[k][k];
+					for (int c = k; c <= n; ++c)
+					{
+						Hn[r][c] -= fct * Hn[k][c];
+					}
+				}
+			}
+			for (int k = n - 1; k >= 0 && valid; --k)
+			{
+				double s = Hn[k][n];
+				for (int c = k + 1; c < n; ++c)
+				{
+					s -= Hn[k][c] * step[c];
+				}
+				step[k] = s / Hn[k][k];
+			}
+		}
+		else
+		{
+			valid = qrSolve(A, m + n, n, b, step);
+		}
 		if (valid)
 		{
 			for (int c = 0; c < n; ++c)
