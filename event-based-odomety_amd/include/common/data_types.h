@@ -7,6 +7,7 @@
 #pragma once
 
 #include <chrono>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <deque>
@@ -35,6 +36,37 @@ struct Point2d
 };
 
 using timestamp_t = std::chrono::microseconds;
+
+// Sophus::SE2d stand-in for common::Pose2d (common/include/common/geometry.h): the storage
+// the tracker hands to Ceres — unit complex (cos, sin), then the translation — and the few
+// operations the tracker path calls (matrix2x3, inverse, data).
+struct Pose2d
+{
+	double d[4] = {1.0, 0.0, 0.0, 0.0};
+	Pose2d() = default;
+	Pose2d(double theta, const Point2d& t);
+	double* data() { return d; }
+	const double* data() const { return d; }
+	struct Matrix2x3
+	{
+		double m[2][3];
+		double operator()(int r, int c) const { return m[r][c]; }
+	};
+	Matrix2x3 matrix2x3() const
+	{
+		return Matrix2x3{{{d[0], -d[1], d[2]}, {d[1], d[0], d[3]}}};
+	}
+	Pose2d inverse() const
+	{
+		Pose2d r;
+		const double c = d[0], s = -d[1];
+		r.d[0] = c;
+		r.d[1] = s;
+		r.d[2] = -(c * d[2] - s * d[3]);
+		r.d[3] = -(s * d[2] + c * d[3]);
+		return r;
+	}
+};
 
 template <typename T>
 struct Sample
@@ -82,6 +114,14 @@ inline std::vector<ebo_event> toEboEvents(const Container& events)
 		out.push_back(r);
 	}
 	return out;
+}
+
+inline Pose2d::Pose2d(double theta, const Point2d& t)
+{
+	d[0] = std::cos(theta);
+	d[1] = std::sin(theta);
+	d[2] = t.x;
+	d[3] = t.y;
 }
 
 }  // namespace common

@@ -1,0 +1,157 @@
+// feature_tracker/patch.h — tracker::Patch with the reference's names
+// (implementation/feature_tracker/include/feature_tracker/patch.h:15-160,
+// src/patch.cpp:8-63,156-330), for the per-feature tracker path: the state
+// a tracked feature carries between two Optimizer::optimize calls.  Bookkeeping only — the
+// event window, the rect, the warp and the trajectory; the per-pixel work (integrateEvents,
+// integrateMotionCompensatedEvents, the optimisation) is done for all patches at once by
+// tracker::Optimizer through the C ABI.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <deque>
+#include <vector>
+
+#include "../common/data_types.h"
+#include "feature_detector.h"
+
+namespace tracker
+{
+using Corner = common::Point2d;
+using TrackId = int32_t;
+
+// cv::Rect2d stand-in; contains() is half-open on the integer point, as cv::Rect_::contains.
+struct Rect2d
+{
+	double x = 0, y = 0, width = 0, height = 0;
+	Rect2d() = default;
+	Rect2d(double x_, double y_, double w_, double h_) : x(x_), y(y_), width(w_), height(h_) {}
+	bool contains(const common::Point2i& p) const
+	{
+		return x <= p.x && p.x < x + width && y <= p.y && p.y < y + height;
+	}
+};
+
+class Patch
+{
+   public:
+	// patch.cpp:8-16
+	Patch(const Corner& corner, int extent, const common::timestamp_t& timestamp) : currentTimestamp_(timestamp)
+	{
+		patch_ = Rect2d(corner.x - extent, corner.y - extent, 2 * extent + 1, 2 * extent + 1);
+		init();
+	}
+
+	// patch.cpp:18-36
+	void init()
+	{
+		init_ = false;
+		lost_ = false;
+		trackId_ = -1;
+		numOfEvents_ = 75;
+		initPoint_ = toCorner();
+		counter_ = 0;
+		integratedNabla_ = Mat64(static_cast<int>(patch_.height), static_cast<int>(patch_.width));
+		motionCompensatedIntegratedNabla_ = Mat64(static_cast<int>(patch_.height), static_cast<int>(patch_.width));
+		timeWithoutUpdate_ = common::timestamp_t(static_cast<int64_t>(1e7));
+		initTime_ = currentTimestamp_;
+		addTrajectoryPosition();
+	}
+
+	// patch.cpp:38-47: newest event at the front, window capped at numOfEvents_
+	void addEvent(const common::EventSample& event)
+	{
+		events_.push_front(event);
+		while (events_.size() > numOfEvents_)
+		{
+			events_.pop_back();
+		}
+		counter_++;
+	}
+
+	// patch.cpp:49-63
+	void updatePatchRect()
+	{
+		const auto warpInv = warp_.inverse().matrix2x3();
+		const double newCenterX = warpInv(0, 0) * initPoint_.x + warpInv(0, 1) * initPoint_.y + warpInv(0, 2);
+		const double newCenterY = warpInv(1, 0) * initPoint_.x + warpInv(1, 1) * initPoint_.y + warpInv(1, 2);
+		const int extentX = static_cast<int>((patch_.width - 1) / 2);
+		const int extentY = static_cast<int>((patch_.height - 1) / 2);
+		patch_ = Rect2d(newCenterX - extentX, newCenterY - extentY, 2 * extentX + 1, 2 * extentY + 1);
+	}
+
+	void resetBatch() { counter_ = 0; }
+	void addTrajectoryPosition() { trajectory_.push_back({toCorner(), currentTimestamp_}); }
+	void addFinalCost(double finalCost) { finalCosts_.emplace_back(finalCost); }
+	Corner toCorner() const { return Corner(patch_.x + (patch_.width - 1) / 2., patch_.y + (patch_.height - 1) / 2.); }
+	bool isInPatch(const common::Point2i& point) const { return patch_.contains(point); }
+	bool isReady() const { return counter_ >= 30 && events_.size() >= numOfEvents_; }
+	bool isLost() const { return lost_; }
+	bool isInit() const { return init_; }
+
+	common::EventSequence const& getEvents() const { return events_; }
+	Mat64 const& getIntegratedNabla() const { return integratedNabla_; }
+	Mat64 const& getCompenatedIntegratedNabla() const { return motionCompensatedIntegratedNabla_; }
+	Rect2d const& getPatch() const { return patch_; }
+	TrackId getTrackId() const { return trackId_; }
+	const common::Pose2d& getWarp() const { return warp_; }
+	float getFlow() const { return static_cast<float>(flowDir_); }  // float, as the reference (patch.h:56)
+	std::vector<common::Sample<common::Point2d>> const& getTrajectory() const { return trajectory_; }
+	size_t getNumOfEvents() const { return numOfEvents_; }
+	common::timestamp_t getCurrentTimestamp() const { return currentTimestamp_; }
+	common::timestamp_t getTimeWithoutUpdate() const { return timeWithoutUpdate_; }
+	common::timestamp_t getTimeLastUpdate() const { return timeLastUpdate_; }
+	common::timestamp_t getInitTime() const { return initTime_; }
+	const std::vector<double>& getFinalCosts() const { return finalCosts_; }
+
+	void setLost() { lost_ = true; }
+	void setNumOfEvents(size_t numOfEvents)
+	{
+		numOfEvents_ = std::max(minNumOfEvents_, numOfEvents);
+		numOfEvents_ = std::min(numOfEvents_, maxNumOfEvents_);
+	}
+	void setTrackId(TrackId trackId) { trackId_ = trackId; }
+	void setFlowDir(const double flowDir)
+	{
+		flowDir_ = flowDir;
+		init_ = true;
+	}
+	void setWarp(const common::Pose2d& warp)
+	{
+		warp_ = warp;
+		init_ = true;
+	}
+	void setTs(const common::timestamp_t& ts) { currentTimestamp_ = ts; }
+	void setTimeWithoutUpdate(const common::timestamp_t& t) { timeWithoutUpdate_ = t; }
+	void setIntegratedNabla(const Mat64& m) { integratedNabla_ = m; }
+	void setMotionCompensatedIntegratedNabla(const Mat64& m) { motionCompensatedIntegratedNabla_ = m; }
+	void setTimestamps(common::timestamp_t current, common::timestamp_t lastUpdate)
+	{
+		currentTimestamp_ = current;  // what integrateEvents leaves (patch.cpp:78-84)
+		timeLastUpdate_ = lastUpdate;
+	}
+
+   private:
+	bool init_ = false;
+	bool lost_ = false;
+	Rect2d patch_;
+	common::Point2d initPoint_;
+	TrackId trackId_ = -1;
+	common::timestamp_t currentTimestamp_{0};
+	common::timestamp_t timeLastUpdate_{0};
+	common::timestamp_t timeWithoutUpdate_{0};
+	common::timestamp_t initTime_{0};
+	common::EventSequence events_;
+	size_t numOfEvents_ = 75;
+	size_t minNumOfEvents_ = 100;
+	size_t maxNumOfEvents_ = 300;
+	size_t counter_ = 0;
+	Mat64 integratedNabla_;
+	Mat64 motionCompensatedIntegratedNabla_;
+	double flowDir_ = 0.0;
+	common::Pose2d warp_;
+	std::vector<common::Sample<common::Point2d>> trajectory_;
+	std::vector<double> finalCosts_;
+};
+
+}  // namespace tracker

@@ -3,6 +3,7 @@
 // evaluator drives it (tools/evaluator/src/evaluator.cpp:32-45), checked against the
 // CPU oracle.  Mirrors the style of the reference's own gtest files; gtest is not in
 // this image, so plain checks.  Run by tests/test_gpu_facade.py on the GPU box.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,7 @@
 
 #include "../../event-based-odomety_amd/include/feature_tracker/contrast_functor.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/feature_detector.h"
+#include "../../event-based-odomety_amd/include/feature_tracker/optimizer.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/total_variance.h"
 #include "../../event-based-odomety_amd/include/tools/event_pump.h"
 #include "../../oracle/ebo_oracle.h"
@@ -325,6 +327,156 @@ int main()
 		// first window closes at 15000 events; the remaining 5000 events stay pending
 		EXPECT_TRUE(pump.windows() == 1 && seen == 1 && lastN == 15000);
 		EXPECT_TRUE(det2.getEvents().size() == 5000);
+	}
+
+	// ---- tracker::Optimizer::optimize over tracked patches (optimizer.cpp:62-206) ------------
+	{
+		const int W = 240, H = 180;
+		tracker::Mat64 gx(H, W), gy(H, W);
+		std::vector<double> grid(static_cast<size_t>(W) * H * 2);
+		for (int y = 0; y < H; ++y)
+		{
+			for (int x = 0; x < W; ++x)
+			{
+				// gradient of a few smooth blobs
+				double vx = 0, vy = 0;
+				for (int k = 0; k < 5; ++k)
+				{
+					const double cx = 40 + 38 * k, cy = 40 + 25 * k, sg = 6 + k;
+					const double e = std::exp(-((x - cx) * (x - cx) + (y - cy) * (y - cy)) / (2 * sg * sg));
+					vx += -(x - cx) / (sg * sg) * e;
+					vy += -(y - cy) / (sg * sg) * e;
+				}
+				gx.at<double>(y, x) = vx;
+				gy.at<double>(y, x) = vy;
+				grid[2 * (static_cast<size_t>(y) * W + x)] = vx;
+				grid[2 * (static_cast<size_t>(y) * W + x) + 1] = vy;
+			}
+		}
+		tracker::OptimizerParams op;
+		tracker::Optimizer optimizer(op, tracker::Size(W, H));
+		optimizer.setGrad(gx, gy);
+		std::vector<tracker::Patch> patchStore;
+		patchStore.reserve(8);
+		// (a fifth blob at k = 4 drives the LM to a 90-degree rotation with the patch half outside
+		// the image, where two correct solvers stop agreeing; see tests/test_optimizer.py)
+		for (int k = 0; k < 4; ++k)
+		{
+			patchStore.emplace_back(tracker::Corner(42.0 + 38 * k, 38.0 + 25 * k), 12, common::timestamp_t(1000));
+			tracker::Patch& p = patchStore.back();
+			p.setTrackId(k);
+			p.setNumOfEvents(120);
+			p.setFlowDir(0.4 + 0.3 * k);
+			// one event on each of the 280 pixels where the predicted nabla (gradient projected on
+			// the flow, sampled one pixel off) is strongest, with the opposite sign: a well-posed
+			// tracking problem whose answer is a shift of about one pixel
+			const double fc = std::cos(0.4 + 0.3 * k), fs = std::sin(0.4 + 0.3 * k);
+			std::vector<std::pair<double, int>> strength;
+			for (int y = 0; y < 25; ++y)
+			{
+				for (int x = 0; x < 25; ++x)
+				{
+					const int ix = 30 + 38 * k + x + 1, iy = 26 + 25 * k + y;
+					strength.push_back({-std::fabs(gx.at<double>(iy, ix) * fc + gy.at<double>(iy, ix) * fs), y * 25 + x});
+				}
+			}
+			std::sort(strength.begin(), strength.end());
+			p.setNumOfEvents(280);
+			for (int i = 0; i < 280; ++i)
+			{
+				const int x = strength[i].second % 25, y = strength[i].second / 25;
+				const int ix = 30 + 38 * k + x + 1, iy = 26 + 25 * k + y;
+				const double pred = gx.at<double>(iy, ix) * fc + gy.at<double>(iy, ix) * fs;
+				common::EventSample e;
+				e.value.point = {30 + 38 * k + x, 26 + 25 * k + y};
+				e.value.sign = pred < 0 ? common::POSITIVE : common::NEGATIVE;
+				e.timestamp = common::timestamp_t(2000 + 40 * i);
+				p.addEvent(e);
+			}
+		}
+		std::vector<tracker::Patch*> batch;
+		for (auto& p : patchStore)
+		{
+			batch.push_back(&p);
+		}
+		// the oracle's version of the same sequence, from copies of the patches' state
+		struct Expect
+		{
+			std::vector<double> nabla, mc;
+			double pose[4], flow, rect[4];
+			orc_summary sum;
+			int32_t updated;
+		};
+		std::vector<Expect> ex(batch.size());
+		for (size_t i = 0; i < batch.size(); ++i)
+		{
+			const tracker::Patch& p = *batch[i];
+			std::vector<orc_event> pe;
+			for (const auto& e : p.getEvents())
+			{
+				pe.push_back({e.value.point.x, e.value.point.y, static_cast<int32_t>(e.value.sign), 0, e.timestamp.count()});
+			}
+			const tracker::Rect2d r = p.getPatch();
+			Expect& E = ex[i];
+			E.nabla.assign(25 * 25, 0.0);
+			int64_t cur = 0, last = 0;
+			orc_patch_integrate(pe.data(), pe.size(), r.x, r.y, r.width, r.height, E.nabla.data(), &cur, &last);
+			std::vector<double> nn(25 * 25);
+			orc_normalize_nabla(E.nabla.data(), 25 * 25, nn.data());
+			std::copy(p.getWarp().data(), p.getWarp().data() + 4, E.pose);
+			E.flow = p.getFlow();
+			orc_optimizer_solve(grid.data(), W, H, r.x, r.y, r.width, r.height, nn.data(), op.huberLoss, nullptr, E.pose,
+								&E.flow, &E.sum);
+			E.flow = std::fmod(E.flow, 2 * M_PI);
+			const tracker::Corner c0 = p.toCorner();
+			orc_patch_update_rect(E.pose, c0.x, c0.y, r.width, r.height, E.rect);  // initPoint_ == first corner
+			const double nc[2] = {E.rect[0] + 12.0, E.rect[1] + 12.0};
+			const double pc[2] = {c0.x, c0.y};
+			E.mc.assign(25 * 25, 0.0);
+			orc_patch_integrate_mc(pe.data(), pe.size(), E.rect[0], E.rect[1], E.rect[2], E.rect[3], pc, 1000, nc, cur,
+								   cur, E.mc.data(), &E.updated);
+		}
+		optimizer.optimize(batch);
+		EXPECT_TRUE(optimizer.getFinalCosts().size() == batch.size());
+		for (size_t i = 0; i < batch.size(); ++i)
+		{
+			const tracker::Patch& p = *batch[i];
+			const Expect& E = ex[i];
+			bool sameN = true, sameM = true;
+			for (int k = 0; k < 25 * 25; ++k)
+			{
+				sameN = sameN && p.getIntegratedNabla().ptr()[k] == E.nabla[k];
+				sameM = sameM && p.getCompenatedIntegratedNabla().ptr()[k] == E.mc[k];
+			}
+			std::printf("Optimizer patch %zu: cost %.12g vs oracle %.12g (initial %.6g), iterations %d vs %d, "
+						"warp (%.9f %.9f %.9f %.9f) vs (%.9f %.9f %.9f %.9f)\n",
+						i, p.getFinalCosts().back(), E.sum.final_cost, E.sum.initial_cost,
+						optimizer.getLastSummaries()[i].iterations, E.sum.iterations, p.getWarp().data()[0],
+						p.getWarp().data()[1], p.getWarp().data()[2], p.getWarp().data()[3], E.pose[0], E.pose[1],
+						E.pose[2], E.pose[3]);
+			EXPECT_TRUE(sameN);  // integer counts: bit exact
+			EXPECT_TRUE(E.updated == 1 && sameM);
+			EXPECT_TRUE(optimizer.getLastSummaries()[i].iterations == E.sum.iterations);
+			EXPECT_NEAR(p.getFinalCosts().back(), E.sum.final_cost, 1e-7 * E.sum.final_cost + 1e-13);
+			for (int k = 0; k < 4; ++k)
+			{
+				EXPECT_NEAR(p.getWarp().data()[k], E.pose[k], 1e-5);
+			}
+			EXPECT_NEAR(static_cast<double>(p.getFlow()), static_cast<double>(static_cast<float>(E.flow)), 1e-5);
+			EXPECT_NEAR(p.getPatch().x, E.rect[0], 1e-5);
+			EXPECT_NEAR(p.getPatch().y, E.rect[1], 1e-5);
+			EXPECT_TRUE(p.getTrajectory().size() == 2);
+			EXPECT_TRUE(!p.isLost() && p.isInit());
+		}
+		// optimize(Patch&): the reference's signature, one patch
+		tracker::Patch single(tracker::Corner(80.0, 63.0), 12, common::timestamp_t(1000));
+		single.setFlowDir(1.0);
+		for (const auto& e : patchStore[1].getEvents())
+		{
+			single.addEvent(e);
+		}
+		optimizer.optimize(single);
+		EXPECT_TRUE(single.getFinalCosts().size() == 1 && single.getTrajectory().size() == 2);
 	}
 
 	std::printf(g_fail ? "facade_test: %d FAILED\n" : "facade_test: all passed\n", g_fail);
