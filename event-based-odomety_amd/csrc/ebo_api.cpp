@@ -13,6 +13,11 @@
 #include <string>
 #include <vector>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "../../include/ebo.h"
 #include "ebo_internal.h"
 #include "field_tv.h"
@@ -63,6 +68,9 @@ struct ebo_ctx
 	double* d_image = nullptr;
 	void* d_aux = nullptr;
 	size_t aux_cap = 0;
+	unsigned char* d_modes = nullptr;        // per-flow-slot evaluation modes of a lock-step solve
+	size_t modes_cap = 0;
+	const unsigned char* modes_active = nullptr;  // non-null only inside eval_host(modes)
 	double2* d_opt_grid = nullptr;   // Optimizer::setGrad's interleaved gradient grid [H][W]
 	bool opt_grid_valid = false;
 	void* d_opt = nullptr;           // scratch of ebo_optimizer_eval / _solve
@@ -331,6 +339,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 {
 	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
 	EdgeLaunch L;
+	L.d_modes = c->modes_active;
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
@@ -427,6 +436,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	}
 	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
 	EvalLaunch L;
+	L.d_modes = c->modes_active;
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
@@ -478,7 +488,10 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	return EBO_OK;
 }
 
-int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac)
+// modes (optional, [n_flows]): 0 = slot not wanted this round (r / jac left as they are),
+// 1 = value only, 2 = value + Jacobian; lets a lock-step solve skip finished problems and
+// Jacobians nobody asked for.
+int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const unsigned char* modes = nullptr)
 {
 	const size_t nf = c->n_flows();
 	int rc = c->hip(hipMemcpyAsync(c->d_flows, flows, nf * 2 * sizeof(double),
@@ -488,7 +501,32 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac)
 	{
 		return rc;
 	}
+	if (modes)
+	{
+		if (nf > c->modes_cap)
+		{
+			if (c->d_modes)
+			{
+				hipFree(c->d_modes);
+				c->d_modes = nullptr;
+				c->modes_cap = 0;
+			}
+			rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_modes), nf), "hipMalloc modes");
+			if (rc)
+			{
+				return rc;
+			}
+			c->modes_cap = nf;
+		}
+		rc = c->hip(hipMemcpyAsync(c->d_modes, modes, nf, hipMemcpyHostToDevice, c->stream), "H2D modes");
+		if (rc)
+		{
+			return rc;
+		}
+		c->modes_active = c->d_modes;
+	}
 	rc = run_eval_device(c, c->d_flows, jac != nullptr, c->d_out);
+	c->modes_active = nullptr;
 	if (rc)
 	{
 		return rc;
@@ -508,6 +546,10 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac)
 	}
 	for (size_t i = 0; i < nf; ++i)
 	{
+		if (modes && modes[i] == 0)
+		{
+			continue;
+		}
 		r[i] = c->h_out[3 * i];
 		if (jac)
 		{
@@ -517,6 +559,112 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac)
 	}
 	return EBO_OK;
 }
+
+// A small process-wide pool for the host side of lock-step solves: the per-window LM state
+// machines are independent, and with hundreds of windows their linear algebra is what bounds a
+// round (measured: 256 windows of the reference configuration, 10 us per window-round).
+class HostPool
+{
+   public:
+	static HostPool& get()
+	{
+		static HostPool pool;
+		return pool;
+	}
+	// fn(begin, end) over [0, n) in contiguous chunks; the caller works too.
+	template <class F>
+	void parallel_for(size_t n, size_t minPerThread, F&& fn)
+	{
+		const size_t maxT = workers_.size() + 1;
+		size_t T = std::min(maxT, std::max<size_t>(1, n / std::max<size_t>(1, minPerThread)));
+		if (T <= 1)
+		{
+			fn(static_cast<size_t>(0), n);
+			return;
+		}
+		std::function<void(size_t, size_t)> f = fn;
+		const size_t chunk = (n + T - 1) / T;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			job_ = &f;
+			n_ = n;
+			chunk_ = chunk;
+			next_ = 1;  // chunk 0 is the caller's
+			chunks_ = T;
+			pending_ = T - 1;
+			++generation_;
+		}
+		cv_.notify_all();
+		fn(static_cast<size_t>(0), std::min(n, chunk));
+		std::unique_lock<std::mutex> lk(mu_);
+		done_.wait(lk, [&] { return pending_ == 0; });
+		job_ = nullptr;
+	}
+
+   private:
+	HostPool()
+	{
+		unsigned hw = std::thread::hardware_concurrency();
+		const char* v = std::getenv("EBO_HOST_THREADS");
+		size_t want = v ? static_cast<size_t>(std::max(1, std::atoi(v))) : std::min<size_t>(hw ? hw : 1, 16);
+		for (size_t i = 1; i < want; ++i)
+		{
+			workers_.emplace_back([this] { run(); });
+		}
+	}
+	~HostPool()
+	{
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto& t : workers_)
+		{
+			t.join();
+		}
+	}
+	void run()
+	{
+		size_t seen = 0;
+		for (;;)
+		{
+			std::function<void(size_t, size_t)>* job = nullptr;
+			size_t b = 0, e = 0;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] { return stop_ || (generation_ != seen && job_ && next_ < chunks_); });
+				if (stop_)
+				{
+					return;
+				}
+				const size_t k = next_++;
+				if (next_ >= chunks_)
+				{
+					seen = generation_;
+				}
+				job = job_;
+				b = k * chunk_;
+				e = std::min(n_, b + chunk_);
+			}
+			if (b < e)
+			{
+				(*job)(b, e);
+			}
+			std::unique_lock<std::mutex> lk(mu_);
+			if (--pending_ == 0)
+			{
+				done_.notify_all();
+			}
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_;
+	std::function<void(size_t, size_t)>* job_ = nullptr;
+	size_t n_ = 0, chunk_ = 0, next_ = 0, chunks_ = 0, pending_ = 0, generation_ = 0;
+	bool stop_ = false;
+};
 
 SolveConsts make_solve_consts(const ebo_solver_opts* o)
 {
@@ -619,6 +767,7 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 			{
 				hipFree(c->d_count_ovf);
 	hipFree(c->d_opt_grid);
+	hipFree(c->d_modes);
 	hipFree(c->d_opt);
 				c->d_count_ovf = nullptr;
 				c->count_ovf_cap = 0;
@@ -677,31 +826,46 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 	}
 	std::vector<double> flows(static_cast<size_t>(Wn) * P * 2, 0.0);
 	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
+	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
+	HostPool& pool = HostPool::get();
 	for (;;)
 	{
-		bool any = false, anyJac = false;
+		// every window says what it wants next (its own point, value or value + Jacobian);
+		// finished windows drop out of the launch
+		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
+			for (size_t w = b; w < e; ++w)
+			{
+				const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
+				wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+				std::memset(&modes[w * P], wmode[w], static_cast<size_t>(P));
+			}
+		});
+		bool any = false, anyJac = false, uniform = true;
 		for (int w = 0; w < Wn; ++w)
 		{
-			const HostLm::Request q = lm[w].request(&flows[static_cast<size_t>(w) * P * 2]);
-			if (q != HostLm::DONE)
-			{
-				any = true;
-				anyJac = anyJac || (q == HostLm::NEED_JACOBIAN);
-			}
+			any = any || wmode[w] != 0;
+			anyJac = anyJac || wmode[w] == 2;
+			uniform = uniform && wmode[w] == wmode[0];
 		}
 		if (!any)
 		{
 			break;
 		}
-		int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr);
+		// all windows in the same phase (always so for a single window): no mode table needed
+		int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr, uniform ? nullptr : modes.data());
 		if (rc)
 		{
 			return rc;
 		}
-		for (int w = 0; w < Wn; ++w)
-		{
-			lm[w].supply(&r[static_cast<size_t>(w) * P], anyJac ? &J[static_cast<size_t>(w) * P * 2] : nullptr);
-		}
+		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
+			for (size_t w = b; w < e; ++w)
+			{
+				if (wmode[w] != 0)
+				{
+					lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
+				}
+			}
+		});
 	}
 	int worst = 0;
 	for (int w = 0; w < Wn; ++w)

@@ -97,6 +97,7 @@ struct EvalLaunch
 	double* d_partials;    // [flow sets][n_units][tiles][kPartialStride]
 	double* d_out;         // [n_flow][3]
 	double fd_step;        // > 0: combine as central differences
+	const unsigned char* d_modes = nullptr;  // per flow slot: 0 skip, 1 value, 2 value + Jacobian (impl 3, fused path)
 	EvalConsts c;
 };
 int launch_eval_variance(const EvalLaunch& L, void* stream);
@@ -129,6 +130,7 @@ struct EdgeLaunch
 	size_t scratch_stride;
 	double* d_sets;       // staging [5][n_units][3] for central differences
 	double* d_out;        // [n_flow][3]
+	const unsigned char* d_modes = nullptr;  // per flow slot: 0 skip, 1 value, 2 value + Jacobian
 	EvalConsts c;
 	EdgeConsts ec;
 };

@@ -1633,7 +1633,8 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		}
 		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
 						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
-						   L.d_partials, L.d_out, L.c);
+						   L.d_partials, L.d_out, L.c,
+						   (L.tiles == 1 && L.flow_sets == 1) ? L.d_modes : nullptr);
 	}
 	else
 	{
@@ -1924,7 +1925,7 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 	}
 	hipLaunchKernelGGL(k_eval_edge, dim3(L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
 					   L.d_events, L.d_units, L.d_flows, L.want_jac, L.cap_px, L.fd_step, L.d_scratch,
-					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec);
+					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec, L.flow_sets == 1 ? L.d_modes : nullptr);
 	if (check_launch())
 	{
 		return -2;
