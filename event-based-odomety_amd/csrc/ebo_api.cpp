@@ -917,31 +917,42 @@ int solve_independent_lockstep(ebo_ctx* c, const ebo_solver_opts* o, double* flo
 		}
 	}
 	std::vector<double> flows(nf * 2, 0.0), r(nf), J(nf * 2);
+	std::vector<unsigned char> modes(nf, 0);
+	HostPool& pool = HostPool::get();
 	for (;;)
 	{
+		// every patch says what it wants next; finished patches drop out of the launch
+		pool.parallel_for(lms.size(), 256, [&](size_t b, size_t e) {
+			for (size_t k = b; k < e; ++k)
+			{
+				const HostLm::Request q = lms[k].request(&flows[2 * slot[k]]);
+				modes[slot[k]] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+			}
+		});
 		bool any = false, anyJac = false;
 		for (size_t k = 0; k < lms.size(); ++k)
 		{
-			const HostLm::Request q = lms[k].request(&flows[2 * slot[k]]);
-			if (q != HostLm::DONE)
-			{
-				any = true;
-				anyJac = anyJac || (q == HostLm::NEED_JACOBIAN);
-			}
+			any = any || modes[slot[k]] != 0;
+			anyJac = anyJac || modes[slot[k]] == 2;
 		}
 		if (!any)
 		{
 			break;
 		}
-		const int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr);
+		const int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr, modes.data());
 		if (rc)
 		{
 			return rc;
 		}
-		for (size_t k = 0; k < lms.size(); ++k)
-		{
-			lms[k].supply(&r[slot[k]], anyJac ? &J[2 * slot[k]] : nullptr);
-		}
+		pool.parallel_for(lms.size(), 256, [&](size_t b, size_t e) {
+			for (size_t k = b; k < e; ++k)
+			{
+				if (modes[slot[k]] != 0)
+				{
+					lms[k].supply(&r[slot[k]], modes[slot[k]] == 2 ? &J[2 * slot[k]] : nullptr);
+				}
+			}
+		});
 	}
 	std::fill(flows_out, flows_out + nf * 2, 0.0);
 	if (summary)
