@@ -268,6 +268,39 @@ def main():
         extras["edge_loss_value_jacobian"] = {"ms": ems, "windows": We,
                                               "mevents_per_s": int(offsets[We]) / (ems * 1e-3) / 1e6}
         ce.close()
+        # the reference's own call (240x180, 20x20 patches, 15 k events, edge loss, TV-coupled
+        # global LM: FeatureDetector::compensateEventsContrast as shipped), 64 windows in lock step
+        rcfg = dict(name="reference default", image=(240, 180), patch=(20, 20), events=15000, index=0)
+        rev, roff, _ = synth.make_stream(rcfg, 64)
+        cr = ebo.Context(device=local, image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE,
+                         max_events=len(rev), max_windows=64)
+        cr.set_windows(rev, roff)
+        cr.solve(ebo.default_solver())
+        t0 = time.perf_counter()
+        _, rs = cr.solve(ebo.default_solver())
+        t_ref = time.perf_counter() - t0
+        extras["reference_default_call"] = {"windows": 64, "ms_per_window": t_ref * 1e3 / 64,
+                                            "iterations": rs[0].iterations}
+        cr.close()
+        # per-feature tracker objective (Optimizer::optimize's solve), 100 tracked 25x25 patches
+        rng = np.random.default_rng(7)
+        ys, xs = np.mgrid[0:180, 0:240].astype(np.float64)
+        img = sum(rng.uniform(-1, 1) * np.exp(-((xs - rng.uniform(0, 240)) ** 2 + (ys - rng.uniform(0, 180)) ** 2)
+                                              / (2 * rng.uniform(3, 9) ** 2)) for _ in range(40))
+        gx, gy = np.zeros_like(img), np.zeros_like(img)
+        gx[:, 1:-1] = 0.5 * (img[:, 2:] - img[:, :-2])
+        gy[1:-1, :] = 0.5 * (img[2:, :] - img[:-2, :])
+        co = ebo.Context(device=local, image_w=240, image_h=180)
+        co.optimizer_set_grad(gx, gy)
+        rects = np.stack([rng.uniform(5, 210, 100), rng.uniform(5, 150, 100), np.full(100, 25.0), np.full(100, 25.0)], 1)
+        nablas = [rng.integers(-3, 4, (25, 25)).astype(np.float64) for _ in range(100)]
+        poses = np.tile([1.0, 0.0, 0.0, 0.0], (100, 1))
+        fds = rng.uniform(0, 6.28, 100)
+        co.optimizer_solve(rects, nablas, poses, fds, normalize=True)
+        t0 = time.perf_counter()
+        co.optimizer_solve(rects, nablas, poses, fds, normalize=True)
+        extras["tracker_optimizer_solve"] = {"patches": 100, "ms": (time.perf_counter() - t0) * 1e3}
+        co.close()
 
     if rank == 0:
         base = cpu_baseline(synth, args.config, args.cpu_seconds) if world == 1 else None

@@ -560,16 +560,26 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 	return EBO_OK;
 }
 
-// A small process-wide pool for the host side of lock-step solves: the per-window LM state
-// machines are independent, and with hundreds of windows their linear algebra is what bounds a
-// round (measured: 256 windows of the reference configuration, 10 us per window-round).
+// A small thread pool for the host side of lock-step solves: the per-window LM state machines
+// are independent, and with hundreds of windows their linear algebra is what bounds a round
+// (measured: 256 windows of the reference configuration, 10 us per window-round).  The pool
+// lives for ONE solve call (threads are created when the call has enough independent problems
+// and joined before it returns): no thread of this library outlives an API call, so process
+// exit, dlclose and profilers that wrap the process never meet a parked worker.
 class HostPool
 {
    public:
-	static HostPool& get()
+	// problems: independent state machines of the call; perThread: how many make a thread worth it
+	HostPool(size_t problems, size_t perThread)
 	{
-		static HostPool pool;
-		return pool;
+		unsigned hw = std::thread::hardware_concurrency();
+		const char* v = std::getenv("EBO_HOST_THREADS");
+		size_t want = v ? static_cast<size_t>(std::max(1, std::atoi(v))) : std::min<size_t>(hw ? hw : 1, 16);
+		want = std::min(want, std::max<size_t>(1, problems / std::max<size_t>(1, perThread)));
+		for (size_t i = 1; i < want; ++i)
+		{
+			workers_.emplace_back([this] { run(); });
+		}
 	}
 	// fn(begin, end) over [0, n) in contiguous chunks; the caller works too.
 	template <class F>
@@ -601,17 +611,8 @@ class HostPool
 		job_ = nullptr;
 	}
 
-   private:
-	HostPool()
-	{
-		unsigned hw = std::thread::hardware_concurrency();
-		const char* v = std::getenv("EBO_HOST_THREADS");
-		size_t want = v ? static_cast<size_t>(std::max(1, std::atoi(v))) : std::min<size_t>(hw ? hw : 1, 16);
-		for (size_t i = 1; i < want; ++i)
-		{
-			workers_.emplace_back([this] { run(); });
-		}
-	}
+	HostPool(const HostPool&) = delete;
+	HostPool& operator=(const HostPool&) = delete;
 	~HostPool()
 	{
 		{
@@ -624,6 +625,7 @@ class HostPool
 			t.join();
 		}
 	}
+   private:
 	void run()
 	{
 		size_t seen = 0;
@@ -827,7 +829,7 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 	std::vector<double> flows(static_cast<size_t>(Wn) * P * 2, 0.0);
 	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
 	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
-	HostPool& pool = HostPool::get();
+	HostPool pool(static_cast<size_t>(Wn), 8);
 	for (;;)
 	{
 		// every window says what it wants next (its own point, value or value + Jacobian);
@@ -918,7 +920,7 @@ int solve_independent_lockstep(ebo_ctx* c, const ebo_solver_opts* o, double* flo
 	}
 	std::vector<double> flows(nf * 2, 0.0), r(nf), J(nf * 2);
 	std::vector<unsigned char> modes(nf, 0);
-	HostPool& pool = HostPool::get();
+	HostPool pool(lms.size(), 256);
 	for (;;)
 	{
 		// every patch says what it wants next; finished patches drop out of the launch
