@@ -349,19 +349,40 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	L.fd_step = central ? c->prm.fd_step : 0.0;
 	// one workgroup per CU (LDS-limited): a big workgroup is the only source of waves
 	// (measured, C2 x 64 windows: 256 threads 2.1, 512: 2.8, 1024: 3.3 Gevents/s)
-	L.block = static_cast<int>(env_size("EBO_EDGE_BLOCK", 1024));
-	if (L.block < 64 || L.block > 1024 || (L.block & 63))
+	L.block = static_cast<int>(env_size("EBO_EDGE_BLOCK", 0));
+	if (L.block != 0 && (L.block < 64 || L.block > 1024 || (L.block & 63)))
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,1024]");
 	}
 	const size_t headerBytes = (168 + 512) * sizeof(double);  // kEdgeHeader
 	const size_t canvasPx = static_cast<size_t>(9) * c->max_rw * c->max_rh;
+	// Two LDS layouts (ebo_edge.inc): I, E, A (f64) + cnt (i32) = 28 B per pixel with the
+	// separable tensor filter, one 1024-lane workgroup per CU; or, when the whole canvas then
+	// fits TWICE into a CU's LDS (a 60x60 canvas: 77 KB), I, E/A + cnt = 20 B per pixel with the
+	// direct filter and two 512-lane workgroups per CU (128 VGPRs each: together the CU's
+	// register file) that overlap each other's barriers.  Measured, reference-default
+	// configuration x 256 windows: 4.27 -> 2.64 ms; C2 (canvas 90x66) stays on the first layout
+	// (0.93 ms vs 0.98 / 1.27 ms for the second with the direct / short-band separable filter).
 	const size_t bytesPerPx = 3 * sizeof(double) + sizeof(int32_t);
+	const size_t aliasPerPx = 2 * sizeof(double) + sizeof(int32_t);
+	const char* layoutEnv = std::getenv("EBO_EDGE_LAYOUT");  // 0 / 1 force a layout (A/B)
+	const bool fitsTwice = headerBytes + canvasPx * aliasPerPx + 64 <= 80 * 1024 - 256;
+	L.alias_lds = layoutEnv ? (std::atoi(layoutEnv) != 0) : (fitsTwice ? 1 : 0);
+	const size_t ldsPerPx = L.alias_lds ? aliasPerPx : bytesPerPx;
 	size_t ldsBytes = std::min<size_t>(env_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
 	// no point in reserving more LDS than the whole canvas needs
-	ldsBytes = std::min(ldsBytes, headerBytes + canvasPx * bytesPerPx + 64);
-	L.cap_px = static_cast<int>((ldsBytes - headerBytes) / bytesPerPx);
-	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * bytesPerPx;
+	ldsBytes = std::min(ldsBytes, headerBytes + canvasPx * ldsPerPx + 64);
+	L.cap_px = static_cast<int>((ldsBytes - headerBytes) / ldsPerPx);
+	if (L.block == 0)
+	{
+		L.block = (L.alias_lds && headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx <= 80 * 1024 - 256) ? 512 : 1024;
+	}
+	if (L.alias_lds)
+	{
+		// the in-LDS list compaction keeps 8 counts per thread in registers
+		L.cap_px = std::min(L.cap_px, 8 * L.block);
+	}
+	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx;
 	L.scratch_stride = (canvasPx * bytesPerPx + 255) & ~static_cast<size_t>(255);
 	L.d_scratch = nullptr;
 	if (static_cast<size_t>(L.cap_px) < canvasPx)

@@ -125,6 +125,7 @@ struct EdgeLaunch
 	double fd_step;
 	int block;
 	int cap_px;           // pixels per array that fit LDS
+	int alias_lds;        // 1: 20 B/pixel LDS layout (A in E's storage, direct tensor form), 2 workgroups per CU
 	size_t lds_bytes;
 	char* d_scratch;      // global fallback, [flow sets][n_units][stride]
 	size_t scratch_stride;

@@ -1919,11 +1919,12 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 	{
 		return 0;
 	}
-	if (allow_big_lds(k_eval_edge, L.lds_bytes))
+	auto edgeKern = L.alias_lds ? k_eval_edge<true> : k_eval_edge<false>;
+	if (allow_big_lds(edgeKern, L.lds_bytes))
 	{
 		return -2;
 	}
-	hipLaunchKernelGGL(k_eval_edge, dim3(L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
+	hipLaunchKernelGGL(edgeKern, dim3(L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
 					   L.d_events, L.d_units, L.d_flows, L.want_jac, L.cap_px, L.fd_step, L.d_scratch,
 					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec, L.flow_sets == 1 ? L.d_modes : nullptr);
 	if (check_launch())
