@@ -268,6 +268,30 @@ def main():
         extras["edge_loss_value_jacobian"] = {"ms": ems, "windows": We,
                                               "mevents_per_s": int(offsets[We]) / (ems * 1e-3) / 1e6}
         ce.close()
+        # the 1280x720 stream of BASELINE configs[3] (1024 patches, 1 M events per window) on this
+        # one GPU: same kernel, 8 windows per launch
+        c4 = synth.CONFIGS[4]
+        ev4, off4, gt4 = synth.make_stream(4, 8)
+        cc = ebo.Context(device=local, image_w=c4["image"][0], image_h=c4["image"][1], patch_w=c4["patch"][0],
+                         patch_h=c4["patch"][1], loss=ebo.LOSS_VARIANCE, tv_weight=0.0, max_events=len(ev4),
+                         max_windows=8)
+        cc.set_stream(stream.cuda_stream)
+        cc.set_windows(ev4, off4)
+        f4 = torch.from_numpy(gt4 * 0.5).to("cuda")
+        o4 = torch.zeros((8 * cc.P, 3), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            cc.eval_device(f4.data_ptr(), 1, o4.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(10):
+            cc.eval_device(f4.data_ptr(), 1, o4.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms4 = e0.elapsed_time(e1) / 10
+        extras["c4_1280x720_value_jacobian"] = {"ms": ms4, "windows": 8, "patches_per_window": cc.P,
+                                                "mevents_per_s": len(ev4) / (ms4 * 1e-3) / 1e6}
+        cc.close()
+        del ev4, f4, o4
         # the reference's own call (240x180, 20x20 patches, 15 k events, edge loss, TV-coupled
         # global LM: FeatureDetector::compensateEventsContrast as shipped), 64 windows in lock step
         rcfg = dict(name="reference default", image=(240, 180), patch=(20, 20), events=15000, index=0)
