@@ -209,6 +209,23 @@ def read_events_txt(path, cap=1 << 22):
     return out[: n.value].copy()
 
 
+def write_events_bin(path, ev):
+    """Packed binary sidecar (32-byte header + 16 B per event) of an event array."""
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    rc = lib().ebo_write_events_bin(str(path).encode(), _vp(ev), C.c_size_t(len(ev)))
+    if rc:
+        raise EboError(rc, "cannot write %s" % path)
+
+
+def read_events_bin(path, cap=1 << 24):
+    out = np.zeros(cap, dtype=EVENT_DTYPE)
+    n = C.c_size_t()
+    rc = lib().ebo_read_events_bin(str(path).encode(), _vp(out), C.c_size_t(cap), C.byref(n))
+    if rc:
+        raise EboError(rc, "cannot read %s (read %d events before the error)" % (path, n.value))
+    return out[: n.value].copy()
+
+
 def make_events(x, y, t_us, sign=None):
     ev = np.zeros(len(x), dtype=EVENT_DTYPE)
     ev["x"] = x

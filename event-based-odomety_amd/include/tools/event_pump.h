@@ -92,6 +92,33 @@ class EventPump
 		return out;
 	}
 
+	// the packed binary sidecar of the same recording (ebo_write_events_bin): no parsing
+	static std::vector<common::EventSample> readEventsBin(const std::string& path, size_t maxEvents = 1u << 24)
+	{
+		std::vector<ebo_event> raw(maxEvents);
+		size_t n = 0;
+		if (ebo_read_events_bin(path.c_str(), raw.data(), raw.size(), &n) != EBO_OK)
+		{
+			throw std::runtime_error("cannot read " + path);
+		}
+		std::vector<common::EventSample> out(n);
+		for (size_t i = 0; i < n; ++i)
+		{
+			out[i].value.point = {raw[i].x, raw[i].y};
+			out[i].value.sign = raw[i].sign > 0 ? common::POSITIVE : common::NEGATIVE;
+			out[i].timestamp = common::timestamp_t(raw[i].t_us);
+		}
+		return out;
+	}
+	static void writeEventsBin(const std::string& path, const std::vector<common::EventSample>& events)
+	{
+		const std::vector<ebo_event> raw = common::toEboEvents(events);
+		if (ebo_write_events_bin(path.c_str(), raw.data(), raw.size()) != EBO_OK)
+		{
+			throw std::runtime_error("cannot write " + path);
+		}
+	}
+
    private:
 	tracker::FeatureDetector& tracker_;
 	EvaluatorParams params_;

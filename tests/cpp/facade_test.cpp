@@ -307,6 +307,16 @@ int main()
 		EXPECT_TRUE(read.size() == samples.size());
 		EXPECT_TRUE(read[777].value.point.x == samples[777].value.point.x);
 		EXPECT_TRUE(read[777].value.sign == samples[777].value.sign);
+		// the packed binary sidecar gives the same events back without parsing
+		tools::EventPump::writeEventsBin("/tmp/ebo_facade_events.ebo", read);
+		const auto readBin = tools::EventPump::readEventsBin("/tmp/ebo_facade_events.ebo");
+		bool sameBin = readBin.size() == read.size();
+		for (size_t i = 0; i < read.size() && sameBin; ++i)
+		{
+			sameBin = readBin[i].timestamp == read[i].timestamp && readBin[i].value.point.x == read[i].value.point.x &&
+					  readBin[i].value.point.y == read[i].value.point.y && readBin[i].value.sign == read[i].value.sign;
+		}
+		EXPECT_TRUE(sameBin);
 		tracker::DetectorParams p2;
 		p2.loss = EBO_LOSS_VARIANCE;
 		tracker::FeatureDetector det2(p2);

@@ -53,6 +53,42 @@ def test_events_txt_round_trip_and_reader_fixture(ebo, orc, stream_file):
     assert fx["t_us"].tolist() == [0, 11, 50, 55, 80]
 
 
+def test_binary_sidecar_round_trip(ebo, stream_file, tmp_path):
+    """The packed sidecar gives back exactly what the text reader parsed (SURVEY §8(f) #3)."""
+    import time
+    path, _ = stream_file
+    t0 = time.perf_counter()
+    parsed = ebo.read_events_txt(path)
+    t_txt = time.perf_counter() - t0
+    side = str(tmp_path / "events.ebo")
+    ebo.write_events_bin(side, parsed)
+    assert os.path.getsize(side) == 32 + 16 * len(parsed)
+    t0 = time.perf_counter()
+    back = ebo.read_events_bin(side)
+    t_bin = time.perf_counter() - t0
+    assert np.array_equal(back, parsed)
+    assert np.array_equal(ebo.read_events_bin(side, cap=7), parsed[:7])  # capacity respected
+    # the reference's own fixture through the sidecar
+    fx = ebo.read_events_txt(os.path.join(HERE, "golden", "davis_events_fixture.txt"))
+    ebo.write_events_bin(side, fx)
+    assert np.array_equal(ebo.read_events_bin(side), fx)
+    # truncated file, bad magic, unrepresentable event
+    raw = open(side, "rb").read()
+    open(side, "wb").write(raw[:-5])
+    with pytest.raises(ebo.EboError) as ei:
+        ebo.read_events_bin(side)
+    assert ei.value.code == ebo.ERR_RANGE
+    open(side, "wb").write(b"NOTEBOEV" + raw[8:])
+    with pytest.raises(ebo.EboError):
+        ebo.read_events_bin(side)
+    bad = fx.copy()
+    bad["x"][0] = 70000
+    with pytest.raises(ebo.EboError):
+        ebo.write_events_bin(side, bad)
+    print("events.txt parse %.1f Mevents/s, sidecar read %.1f Mevents/s"
+          % (len(parsed) / t_txt / 1e6, len(parsed) / max(t_bin, 1e-9) / 1e6))
+
+
 def test_reader_rejects_bad_sign(ebo, tmp_path):
     p = tmp_path / "events.txt"
     p.write_text("0.000001 1 2 1\n0.000002 3 4 7\n")
