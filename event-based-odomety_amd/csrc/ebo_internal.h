@@ -237,13 +237,37 @@ struct TvfArgs
 	double huber_a;       // 0: no loss (useL1 false); 1e-5: HuberLoss(1e-5)
 	double lm_lo, lm_hi;  // min/max_lm_diagonal
 };
+// One level of the multigrid preconditioner (ebo_fieldtv.inc): a 5-point operator
+// (A x)_i = diag_i x_i - sum_e w_e x_j on a w x h grid, wh / wv = weight of the edge to the right /
+// lower neighbour (0 where there is none).
+struct TvfLevel
+{
+	int w, h;
+	const double* wh;
+	const double* wv;
+	const double* diag;
+	double2* b;   // right-hand side
+	double2* x;   // after pre-smoothing
+	double2* xo;  // after the coarse correction and post-smoothing
+};
+struct TvfMg
+{
+	int levels;          // 0: multigrid off (diagonal preconditioner)
+	TvfLevel lv[12];
+	double* wh_m[12];    // writable views of lv[l].wh / wv / diag (level 0: masked weights only)
+	double* wv_m[12];
+	double* diag_m[12];
+	double omega, kappa;
+	int coarse_sweeps;
+};
 size_t tvf_workspace_bytes(int w, int h);
-void tvf_carve(TvfArgs& A, int w, int h, void* base, double2** xbest);
+void tvf_carve(TvfArgs& A, TvfMg& M, int w, int h, void* base, double2** xbest);
+int launch_tvf_mg_build(const TvfArgs& A, const TvfMg& M, void* stream);
 int launch_tvf_prepare(const TvfArgs& A, const float* d_field, const int* d_fixed, int n_fixed, void* stream);
 int launch_tvf_linearize(const TvfArgs& A, const double2* X, int first, int cost_only, void* stream);
-int launch_tvf_cg_init(const TvfArgs& A, double radius, void* stream);
+int launch_tvf_cg_init(const TvfArgs& A, const TvfMg& M, double radius, void* stream);
 // CG iterations first_iter .. first_iter + iters - 1 (iteration k reads direction buffer k & 1).
-int launch_tvf_cg_iters(const TvfArgs& A, int first_iter, int iters, void* stream);
+int launch_tvf_cg_iters(const TvfArgs& A, const TvfMg& M, int first_iter, int iters, void* stream);
 int launch_tvf_model(const TvfArgs& A, void* stream);
 int launch_tvf_store(const TvfArgs& A, const double2* X, float* d_field, void* stream);
 

@@ -1680,21 +1680,54 @@ int launch_init_field(const FieldLaunch& L, void* stream)
 	return check_launch();
 }
 
+namespace
+{
+// grid sizes of the multigrid levels: halve until <= 256 nodes
+int tvf_mg_dims(int w, int h, int (&lw)[12], int (&lh)[12])
+{
+	int n = 0;
+	lw[0] = w;
+	lh[0] = h;
+	n = 1;
+	while (lw[n - 1] * lh[n - 1] > 256 && n < 12)
+	{
+		lw[n] = (lw[n - 1] + 1) / 2;
+		lh[n] = (lh[n - 1] + 1) / 2;
+		++n;
+	}
+	return n;
+}
+size_t al256(size_t v)
+{
+	return (v + 255) & ~static_cast<size_t>(255);
+}
+}  // namespace
+
 size_t tvf_workspace_bytes(int w, int h)
 {
 	const size_t n = static_cast<size_t>(w) * h;
-	const size_t nAl = (n + 255) & ~static_cast<size_t>(255);
-	return nAl /*mask*/ + 5 * nAl * 8 + 10 * nAl * 16 + 2 * (4 * 1024 * 8) + 256 /*scal*/;
+	const size_t nAl = al256(n);
+	size_t bytes = nAl /*mask*/ + 5 * nAl * 8 + 10 * nAl * 16 + 2 * (4 * 1024 * 8) + 256 /*scal*/;
+	// multigrid: level 0 masked weights + x; levels >= 1 three weight arrays + three vectors
+	int lw[12], lh[12];
+	const int L = tvf_mg_dims(w, h, lw, lh);
+	bytes += 2 * al256(n * 8) + al256(n * 16);
+	for (int l = 1; l < L; ++l)
+	{
+		const size_t nl = static_cast<size_t>(lw[l]) * lh[l];
+		bytes += 3 * al256(nl * 8) + 3 * al256(nl * 16);
+	}
+	return bytes;
 }
 
-void tvf_carve(TvfArgs& A, int w, int h, void* base, double2** xbest)
+void tvf_carve(TvfArgs& A, TvfMg& M, int w, int h, void* base, double2** xbest)
 {
 	const size_t n = static_cast<size_t>(w) * h;
-	const size_t nAl = (n + 255) & ~static_cast<size_t>(255);
+	const size_t nAl = al256(n);
 	char* b = static_cast<char*>(base);
 	auto take = [&](size_t bytes) {
 		char* r = b;
-		b += (bytes + 255) & ~static_cast<size_t>(255);
+		b += al256(bytes);
 		return r;
 	};
 	A.w = w;
@@ -1714,6 +1747,38 @@ void tvf_carve(TvfArgs& A, int w, int h, void* base, double2** xbest)
 	A.partials_rz = reinterpret_cast<double*>(take(4 * 1024 * 8));
 	A.scal = reinterpret_cast<double*>(take(256));
 	A.mask = reinterpret_cast<unsigned char*>(take(nAl));
+	// multigrid hierarchy
+	int lw[12], lh[12];
+	M.levels = tvf_mg_dims(w, h, lw, lh);
+	for (int l = 0; l < M.levels; ++l)
+	{
+		const size_t nl = static_cast<size_t>(lw[l]) * lh[l];
+		TvfLevel& L = M.lv[l];
+		L.w = lw[l];
+		L.h = lh[l];
+		M.wh_m[l] = reinterpret_cast<double*>(take(nl * 8));
+		M.wv_m[l] = reinterpret_cast<double*>(take(nl * 8));
+		if (l == 0)
+		{
+			M.diag_m[0] = A.diag;  // deg + damping, 1 on the pixels that are not free (k_tvf_cg_init)
+			L.b = A.r;             // the CG residual
+			L.x = reinterpret_cast<double2*>(take(nl * 16));
+			L.xo = A.z;            // z = M^-1 r
+		}
+		else
+		{
+			M.diag_m[l] = reinterpret_cast<double*>(take(nl * 8));
+			L.b = reinterpret_cast<double2*>(take(nl * 16));
+			L.x = reinterpret_cast<double2*>(take(nl * 16));
+			L.xo = reinterpret_cast<double2*>(take(nl * 16));
+		}
+		L.wh = M.wh_m[l];
+		L.wv = M.wv_m[l];
+		L.diag = M.diag_m[l];
+	}
+	M.omega = 0.8;
+	M.kappa = 1.8;
+	M.coarse_sweeps = 8;
 }
 
 namespace
@@ -1764,22 +1829,77 @@ int launch_tvf_linearize(const TvfArgs& A, const double2* X, int first, int cost
 	return check_launch();
 }
 
-int launch_tvf_cg_init(const TvfArgs& A, double radius, void* stream)
+namespace
 {
-	hipLaunchKernelGGL(k_tvf_cg_init, dim3(tvf_grid(A.n)), dim3(256), 0, static_cast<hipStream_t>(stream), A, radius);
+// z = M^-1 r by one V(1,1) cycle; the last kernel leaves the r'z partials for the CG.
+void tvf_mg_vcycle(const TvfArgs& A, const TvfMg& M, hipStream_t s)
+{
+	const int L = M.levels;
+	for (int l = 0; l + 1 < L; ++l)
+	{
+		const TvfLevel& f = M.lv[l];
+		const TvfLevel& c = M.lv[l + 1];
+		const int nc = c.w * c.h;
+		hipLaunchKernelGGL(k_mg_down, dim3((nc + 255) / 256), dim3(256), 0, s, f, c.w, c.h, c.b, M.omega);
+	}
+	hipLaunchKernelGGL(k_mg_coarse, dim3(1), dim3(256), 0, s, M.lv[L - 1], M.omega, M.coarse_sweeps);
+	for (int l = L - 2; l >= 0; --l)
+	{
+		const TvfLevel& f = M.lv[l];
+		const TvfLevel& c = M.lv[l + 1];
+		hipLaunchKernelGGL(k_mg_up, dim3(tvf_grid(f.w * f.h)), dim3(256), 0, s, f, c.xo, c.w, M.omega, M.kappa,
+						   l == 0 ? A.partials_rz : nullptr, l == 0 ? A.mask : nullptr);
+	}
+}
+}  // namespace
+
+// The hierarchy of the operator cg_init just defined (weights of this linearisation, damping of
+// this radius), then the first V-cycle (z and r'z of CG iteration 0).
+int launch_tvf_mg_build(const TvfArgs& A, const TvfMg& M, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (M.levels < 2)
+	{
+		return 0;
+	}
+	hipLaunchKernelGGL(k_mg_mask0, dim3(tvf_grid(A.n)), dim3(256), 0, s, A, M.wh_m[0], M.wv_m[0]);
+	for (int l = 0; l + 1 < M.levels; ++l)
+	{
+		const TvfLevel& c = M.lv[l + 1];
+		const int nc = c.w * c.h;
+		hipLaunchKernelGGL(k_mg_coarsen, dim3((nc + 255) / 256), dim3(256), 0, s, M.lv[l], c, M.wh_m[l + 1],
+						   M.wv_m[l + 1], M.diag_m[l + 1]);
+	}
+	tvf_mg_vcycle(A, M, s);
 	return check_launch();
 }
 
-int launch_tvf_cg_iters(const TvfArgs& A, int first_iter, int iters, void* stream)
+int launch_tvf_cg_init(const TvfArgs& A, const TvfMg& M, double radius, void* stream)
+{
+	hipLaunchKernelGGL(k_tvf_cg_init, dim3(tvf_grid(A.n)), dim3(256), 0, static_cast<hipStream_t>(stream), A, radius,
+					   M.levels >= 2 ? 1 : 0);
+	if (check_launch())
+	{
+		return -2;
+	}
+	return launch_tvf_mg_build(A, M, stream);
+}
+
+int launch_tvf_cg_iters(const TvfArgs& A, const TvfMg& M, int first_iter, int iters, void* stream)
 {
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	const unsigned G = tvf_grid(A.n);
+	const int mg = M.levels >= 2 ? 1 : 0;
 	for (int k = first_iter; k < first_iter + iters; ++k)
 	{
 		const double2* pOld = (k & 1) ? A.p1 : A.p0;
 		double2* pNew = (k & 1) ? A.p0 : A.p1;
 		hipLaunchKernelGGL(k_tvf_cg_apply, dim3(G), dim3(256), 0, s, A, pOld, pNew, k);
-		hipLaunchKernelGGL(k_tvf_cg_update, dim3(G), dim3(256), 0, s, A, pNew, k);
+		hipLaunchKernelGGL(k_tvf_cg_update, dim3(G), dim3(256), 0, s, A, pNew, k, mg);
+		if (mg)
+		{
+			tvf_mg_vcycle(A, M, s);
+		}
 	}
 	return check_launch();
 }

@@ -58,9 +58,22 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	FieldTvStats st;
 	TvfArgs A;
+	TvfMg M;
 	std::memset(&A, 0, sizeof(A));
+	std::memset(&M, 0, sizeof(M));
 	double2* xbest = nullptr;
-	tvf_carve(A, w, h, workspace, &xbest);
+	tvf_carve(A, M, w, h, workspace, &xbest);
+	{
+		// EBO_TVF_PRECOND=jacobi: the diagonal preconditioner (A/B, ~30x more CG iterations)
+		const char* pre = std::getenv("EBO_TVF_PRECOND");
+		if (pre && std::strcmp(pre, "jacobi") == 0)
+		{
+			M.levels = 0;
+		}
+	}
+	// iterations between two looks at the residual: multigrid converges in a few tens
+	const char* chunkEnv = std::getenv("EBO_TVF_CG_CHUNK");
+	const int cgChunk = chunkEnv ? std::max(2, std::atoi(chunkEnv) & ~1) : (M.levels >= 2 ? 8 : 32);
 	A.huber_a = use_l1 ? 1e-5 : 0.0;  // feature_detector.cpp:182,187
 	A.lm_lo = o.min_lm_diagonal;
 	A.lm_hi = o.max_lm_diagonal;
@@ -69,8 +82,6 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 	const double cgTol = tolEnv ? std::atof(tolEnv) : 1e-13;
 	const char* capEnv = std::getenv("EBO_TVF_CG_MAX");
 	const int cgMax = capEnv ? std::atoi(capEnv) : 200000;
-	const char* chunkEnv = std::getenv("EBO_TVF_CG_CHUNK");
-	const int cgChunk = chunkEnv ? std::max(2, std::atoi(chunkEnv) & ~1) : 32;
 
 	auto fail = [&](const char* what) {
 		*err = std::string("field TV: ") + what;
@@ -134,7 +145,7 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 	{
 		if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess)
 		{
-			const int lrc = launch_tvf_cg_iters(A, cgChunk, cgChunk, s);
+			const int lrc = launch_tvf_cg_iters(A, M, cgChunk, cgChunk, s);
 			const hipError_t ce = hipStreamEndCapture(s, &gh.g);
 			if (lrc == 0 && ce == hipSuccess && gh.g &&
 				hipGraphInstantiate(&gh.e, gh.g, nullptr, nullptr, 0) == hipSuccess)
@@ -206,7 +217,7 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 		lastSuccessful = false;
 
 		// LevenbergMarquardtStrategy::ComputeStep: (L_w + C) y = -g by CG.
-		if (launch_tvf_cg_init(A, radius, s))
+		if (launch_tvf_cg_init(A, M, radius, s))
 		{
 			return fail("cg init launch");
 		}
@@ -221,7 +232,7 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 					return fail("cg graph launch");
 				}
 			}
-			else if (launch_tvf_cg_iters(A, done, cgChunk, s))
+			else if (launch_tvf_cg_iters(A, M, done, cgChunk, s))
 			{
 				return fail("cg launch");
 			}

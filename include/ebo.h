@@ -227,7 +227,8 @@ int ebo_init_motion_field(ebo_ctx* ctx, int64_t timestamp, int use_average, int 
  * use_l1 = DetectorParams::useL1; fixed points constant) is solved by the same trust-region LM
  * as ceres::Solve with the options of :216-222 (opts == NULL) and the field is overwritten with
  * the result rounded to float32 (:230-239).  All per-pixel work runs on the device; the linear
- * solve of each LM iteration is a conjugate-gradient run to 1e-13 relative residual.
+ * solve of each LM iteration is a multigrid-preconditioned conjugate-gradient run to 1e-13
+ * relative residual.
  * field_out: host float32 [image_h][image_w][2] (may be NULL; the field stays resident for
  * ebo_count_image(EBO_COUNT_FIELD)).  cg_iterations (may be NULL): total CG iterations.
  * EBO_ERR_STATE without a prior ebo_init_motion_field; EBO_ERR_RANGE for a fixed point at pixel
