@@ -1,8 +1,8 @@
 // field_tv.cpp — see field_tv.h.  The iteration is Ceres 2.0's TrustRegionMinimizer with
 // LevenbergMarquardtStrategy and TrustRegionStepEvaluator as published, specialised to the
 // problem of feature_detector.cpp:154-214; the linear solve (SPARSE_NORMAL_CHOLESKY in the
-// reference, :221) is a preconditioned conjugate-gradient run to a relative residual of
-// 1e-13 on the device, i.e. to the accuracy a direct factorisation delivers.
+// reference, :221) is a multigrid-preconditioned conjugate-gradient run to a relative residual
+// of 1e-13 on the device, i.e. to the accuracy a direct factorisation delivers.
 #include "field_tv.h"
 
 #include <algorithm>
