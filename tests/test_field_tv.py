@@ -245,3 +245,19 @@ def test_device_compensate_events_with_smoothed_field(ebo, orc, synth):
     assert np.array_equal(img, img_same_field)  # bit-exact given the same field
     img_o = orc.compensate_events_field(ev, w, h, ref)
     assert np.abs(img - img_o).sum() <= 4  # an ulp of the field can move an event on a rounding boundary
+
+
+@pytest.mark.gpu
+def test_device_field_tv_diagonal_preconditioner_agrees(ebo, orc, monkeypatch):
+    """EBO_TVF_PRECOND=jacobi (the fallback) and the multigrid preconditioner solve the same
+    systems: same LM trajectory, same field, ~20x apart in CG iterations."""
+    w, h = 96, 72
+    traj, field_o, fixed_o = make_case(orc, w, h, 12, 4)
+    _, _, out_mg, s_mg, cg_mg = run_device(ebo, orc, w, h, traj, True, False)
+    monkeypatch.setenv("EBO_TVF_PRECOND", "jacobi")
+    _, _, out_j, s_j, cg_j = run_device(ebo, orc, w, h, traj, True, False)
+    assert (s_mg.iterations, s_mg.termination) == (s_j.iterations, s_j.termination)
+    assert s_mg.final_cost == pytest.approx(s_j.final_cost, rel=1e-10)
+    diff, frac, ok = ulp_report(out_mg, out_j)
+    assert ok and frac <= 1e-3
+    assert cg_j > 5 * cg_mg
