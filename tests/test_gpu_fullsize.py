@@ -1,0 +1,132 @@
+"""GPU tests at BASELINE.json's FULL window sizes (C2 50 k, C3 200 k, C4 1 M events), where the
+oracle is too slow to evaluate whole windows: size-independent properties of the domain plus
+sampled oracle checks.
+
+  * count images: conservation (the image sums to the number of events that land inside),
+    bit-exact agreement with an independent vectorised numpy restatement of the warp loop,
+    additivity of the un-warped image over a split of the events;
+  * objective: invariance under a permutation of the events of a window (canonical bucket
+    order + exact fixed-point accumulation make it BIT-exact), run-to-run determinism, a batch
+    entry equals the window evaluated alone, and a sample of patches against the oracle on
+    exactly that patch's events (rel 1e-9);
+  * every event is accounted for by the bucketing (per-patch counts sum to the in-sensor events).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FULL = [(2, 50_000), (3, 200_000), (4, 1_000_000)]
+
+
+def ctx_for(ebo, synth, config, **kw):
+    cfg = synth.CONFIGS[config]
+    args = dict(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE, tv_weight=0.0)
+    args.update(kw)
+    return ebo.Context(**args)
+
+
+def round_half_away(v):
+    """C round() on an array (exact except at 0.5 - 2^-54, which no synthetic value hits)."""
+    return np.where(np.abs(v) < 0.5, 0.0, np.trunc(v + np.copysign(0.5, v)))
+
+
+def numpy_warped_count(ev, cfg, npx, npy, flows, t_ref, scale=1e-3):
+    """feature_detector.cpp:433-463, vectorised: an independent restatement of the final loop."""
+    w, h = cfg["image"]
+    pw, ph = cfg["patch"]
+    x = ev["x"].astype(np.int64)
+    y = ev["y"].astype(np.int64)
+    px = np.minimum(x // pw, npx - 1)
+    py = np.minimum(y // ph, npy - 1)
+    m = flows[py * npx + px]
+    dt = (t_ref - ev["t_us"]).astype(np.float64)
+    nx = round_half_away(x + dt * scale * m[:, 0]).astype(np.int64)
+    ny = round_half_away(y + dt * scale * m[:, 1]).astype(np.int64)
+    ok = (nx >= 0) & (nx < w) & (ny >= 0) & (ny < h)
+    img = np.zeros((h, w))
+    np.add.at(img, (ny[ok], nx[ok]), 1.0)
+    return img
+
+
+@pytest.mark.parametrize("config,n_events", FULL)
+def test_count_images_full_size(ebo, orc, synth, config, n_events):
+    cfg = synth.CONFIGS[config]
+    ev, gt = synth.make_window(config)
+    assert len(ev) == n_events
+    with ctx_for(ebo, synth, config, max_events=n_events) as c:
+        c.set_window(ev)
+        t_ref, n = c.window_info()
+        assert n == n_events
+        assert t_ref == orc.mid_timestamp(int(ev["t_us"][0]), int(ev["t_us"][-1]))
+        integ = c.count_image(ebo.COUNT_INTEGRATED)[0]
+        assert integ.sum() == n_events  # every synthetic event is inside the sensor
+        ref = np.zeros_like(integ)
+        np.add.at(ref, (ev["y"], ev["x"]), 1.0)
+        assert np.array_equal(integ, ref)
+        flows = gt * 0.8
+        warped = c.count_image(ebo.COUNT_WARPED, flows)[0]
+        assert np.array_equal(warped, numpy_warped_count(ev, cfg, c.npx, c.npy, flows, t_ref))
+        assert warped.sum() <= n_events
+        # every event is in exactly one patch bucket
+        assert sum(c.patch_info(p)[0] for p in range(c.P)) == n_events
+    # additivity of the un-warped image over a split of the events (two windows of one batch)
+    half = n_events // 2
+    with ctx_for(ebo, synth, config, max_events=n_events, max_windows=2) as c:
+        c.set_windows(ev, np.array([0, half, n_events], dtype=np.uint64))
+        parts = c.count_image(ebo.COUNT_INTEGRATED)
+        assert np.array_equal(parts[0] + parts[1], ref)
+
+
+@pytest.mark.parametrize("config,n_events", FULL)
+def test_objective_full_size_properties(ebo, orc, synth, config, n_events):
+    ev, gt = synth.make_window(config)
+    flows = gt * 0.5
+    with ctx_for(ebo, synth, config, max_events=2 * n_events, max_windows=2) as c:
+        c.set_window(ev)
+        r, J = c.eval(flows)
+        r2, J2 = c.eval(flows)
+        assert np.array_equal(r, r2) and np.array_equal(J, J2)  # run-to-run determinism
+        # permutation of the events between the first and the last one: same set, same
+        # reference times => bit-identical objective (canonical order, exact accumulation)
+        rng = np.random.RandomState(config)
+        perm = np.concatenate([[0], 1 + rng.permutation(n_events - 2), [n_events - 1]])
+        c.set_window(ev[perm])
+        rp, Jp = c.eval(flows)
+        assert np.array_equal(r, rp) and np.array_equal(J, Jp)
+        # a batch entry equals the window alone
+        ev2, gt2 = synth.make_window(config, window=1)
+        both = np.concatenate([ev2, ev])
+        c.set_windows(both, np.array([0, len(ev2), len(both)], dtype=np.uint64))
+        rb, Jb = c.eval(np.stack([gt2 * 0.5, flows]))
+        assert np.array_equal(rb[1], r[0]) and np.array_equal(Jb[1], J[0])
+        # a sample of patches against the oracle on exactly their events
+        c.set_window(ev)
+        sample = rng.choice(c.P, size=min(12, c.P), replace=False)
+        for p in sample:
+            x0, y0, pw, ph = c.patch_rect(p % c.npx, p // c.npx)
+            sel = (ev["x"] >= x0) & (ev["x"] < x0 + pw) & (ev["y"] >= y0) & (ev["y"] < y0 + ph)
+            n, active, _ = c.patch_info(p)
+            assert n == int(sel.sum())
+            if not active:
+                assert r[0][p] == 0.0
+                continue
+            ro, Jo = orc.contrast_eval(ev[sel], (x0, y0, pw, ph), flows[p], 1)
+            np.testing.assert_allclose(r[0][p], ro, rtol=1e-9)
+            np.testing.assert_allclose(J[0][p], Jo, rtol=1e-9, atol=1e-10)
+
+
+def test_device_solve_full_size_is_deterministic_and_lowers_the_cost(ebo, synth):
+    """C4: the whole per-patch solve of a 1 M-event window on the device, twice: identical
+    flows, and no patch ends above the cost it started from."""
+    ev, _ = synth.make_window(4)
+    with ctx_for(ebo, synth, 4, max_events=len(ev)) as c:
+        c.set_window(ev)
+        a, sa = c.solve(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=12)
+        b, sb = c.solve(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=12)
+        assert np.array_equal(a, b)
+        r0, _ = c.eval(np.zeros((c.P, 2)), want_jac=False)
+        r1, _ = c.eval(a[0], want_jac=False)
+        assert np.all(r1[0] ** 2 <= r0[0] ** 2 * (1 + 1e-12))
+        assert sa[0].final_cost <= sa[0].initial_cost
