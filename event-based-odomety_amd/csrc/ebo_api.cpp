@@ -469,6 +469,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	L.impl = eval_impl();
 	L.cap_doubles = 0;
 	L.rotate = env_size("EBO_EVAL_ROT", 1) ? 1 : 0;
+	L.deal = env_size("EBO_EVAL_DEAL", 0) ? 1 : 0;
 	int rc;
 	if (L.impl == 0)
 	{

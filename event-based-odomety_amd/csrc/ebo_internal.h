@@ -93,6 +93,7 @@ struct EvalLaunch
 	                       // 2: same with exact fixed-point (u64) accumulation
 	int cap_doubles;       // impl 1/2: image capacity of one workgroup's LDS, in pixels
 	int rotate;            // impl 1/2: per-lane tap rotation in the scatter pass
+	int deal;              // impl 3: re-deal a wave's events over its lanes by LDS bank residue (EBO_EVAL_DEAL)
 	size_t lds_bytes;
 	double* d_partials;    // [flow sets][n_units][tiles][kPartialStride]
 	double* d_out;         // [n_flow][3]

@@ -1626,7 +1626,8 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 	}
 	else if (L.impl >= 3)
 	{
-		auto kern = (L.c.inv_sigsq <= 1.0) ? k_eval3<true> : k_eval3<false>;
+		auto kern = (L.c.inv_sigsq <= 1.0) ? (L.deal ? k_eval3<true, true> : k_eval3<true, false>)
+										   : (L.deal ? k_eval3<false, true> : k_eval3<false, false>);
 		if (allow_big_lds(kern, L.lds_bytes))
 		{
 			return -2;
