@@ -28,11 +28,14 @@
  *   - contrastFunctor value/Jacobian: cross-checked against the digits recorded in
  *     SURVEY.md §8(c) (tests/golden/survey_probe_contrast.json); the reference's own
  *     tests do not exercise it.
- *   - Solver trajectory (Ceres trust-region LM): PARITY UNPINNED.  Ceres is a
- *     third-party dependency (thirdparty/ceres-solver, >=2.0,<2.2, commit unknown) that is
- *     absent here; oracle.cpp restates its published Levenberg-Marquardt trust-region
- *     algorithm (docs "Solving Non-linear Least Squares", TrustRegionMinimizer /
- *     LevenbergMarquardtStrategy / TrustRegionStepEvaluator, v2.0 defaults).
+ *   - Solver (Ceres trust-region LM).  Ceres is a third-party dependency
+ *     (thirdparty/ceres-solver, >=2.0,<2.2, commit unknown) that is absent here; oracle.cpp
+ *     restates its published Levenberg-Marquardt trust-region algorithm (docs "Solving
+ *     Non-linear Least Squares", TrustRegionMinimizer / LevenbergMarquardtStrategy /
+ *     TrustRegionStepEvaluator, v2.0 defaults).  Pinned by the iteration table Ceres' own
+ *     tutorial publishes for Powell's function (orc_lm_powell, every printed digit of all 14
+ *     iterations; tests/golden/ceres_tutorial_powell.json).  Unpinned: non-monotonic steps,
+ *     loss corrector, local parameterisation, last bits.
  *   - Tracker objective (optimizer_oracle.cpp): PARITY UNPINNED.  Ceres' bicubic interpolator
  *     and Sophus' SE2 are restated from their published algorithms; no reference test
  *     exercises Optimizer / OptimizerCostFunctor.
@@ -193,6 +196,13 @@ int orc_init_motion_field(int w, int h, double scale, int use_average, int n_pat
 int orc_interpolate_motion_field(int w, int h, int use_l1, float* field, int n_fixed,
 								 const int32_t* fixed_xy, const orc_solver_opts* opts,
 								 orc_summary* sum);
+
+/* The trust-region LM restatement (oracle.cpp::minimize) run on Powell's singular function as
+ * the Ceres tutorial sets it up, with a per-accepted-step log in the columns of Ceres' progress
+ * table {cost, cost_change, |gradient|, |step|, tr_ratio, tr_radius}: checked against the table
+ * that tutorial publishes (tests/golden/ceres_tutorial_powell.json).  x [4] in/out. */
+int orc_lm_powell(const orc_solver_opts* opts, double* x, double* trace, int cap, int* n_rows,
+				  orc_summary* sum);
 
 /* ---- per-feature tracker objective (optimizer_oracle.cpp) ----------------
  * tracker::OptimizerCostFunctor::operator() (optimizer_cost.h:30-96) as

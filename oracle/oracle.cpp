@@ -668,6 +668,11 @@ bool choleskySolve(std::vector<double>& A, int n, int band, std::vector<double>&
 // (TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy,
 // TrustRegionStepEvaluator); options as feature_detector.cpp:401-410.
 // x is the full [2P] vector; only columns of the reduced problem move.
+// Optional per-iteration log in the columns of ceres::Solver's progress table (cost,
+// cost_change, |gradient| max norm, |step|, tr_ratio, tr_radius): set by orc_lm_powell to check
+// this restatement against the table Ceres' own tutorial publishes.
+thread_local std::vector<double>* g_lmTrace = nullptr;
+
 template <class PB>
 int minimize(PB& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 {
@@ -962,6 +967,11 @@ int minimize(PB& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 			// LevenbergMarquardtStrategy::StepAccepted.
 			radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * quality - 1.0, 3));
 			radius = std::min(o.max_radius, radius);
+			if (g_lmTrace)
+			{
+				const double row[6] = {xCost, costChange, gradMax, stepNorm, quality, radius};
+				g_lmTrace->insert(g_lmTrace->end(), row, row + 6);
+			}
 			decreaseFactor = 2.0;
 			reuseDiagonal = false;
 			// TrustRegionStepEvaluator::StepAccepted(candidate_cost, model_cost_change).
@@ -1015,6 +1025,50 @@ int minimize(PB& pb, const orc_solver_opts& o, double* x, orc_summary* sum)
 	}
 	return 0;
 }
+
+// Powell's singular function as Ceres' tutorial sets it up (docs "Non-linear Least Squares",
+// examples/powell.cc): four parameter blocks of size 1, four residual blocks
+//   f1 = x1 + 10 x2, f2 = sqrt(5) (x3 - x4), f3 = (x2 - 2 x3)^2, f4 = sqrt(10) (x1 - x4)^2,
+// automatic differentiation, no loss.  Used only to pin minimize() against the iteration table
+// that tutorial publishes (tests/golden/ceres_tutorial_powell.json).
+struct PowellProblem
+{
+	std::vector<int> col{0, 1, 2, 3};
+	int ncols = 4, nrows = 4;
+	int evalsCost = 0, evalsJac = 0;
+	void evaluate(const double* x, double* cost, std::vector<double>* res, std::vector<JRow>* jac)
+	{
+		const double d3 = x[1] - 2.0 * x[2], d4 = x[0] - x[3];
+		const double s5 = std::sqrt(5.0), s10 = std::sqrt(10.0);
+		const double f[4] = {x[0] + 10.0 * x[1], s5 * (x[2] - x[3]), d3 * d3, s10 * d4 * d4};
+		*cost = 0.5 * (f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3]);
+		if (res)
+		{
+			res->assign(f, f + 4);
+		}
+		if (jac)
+		{
+			evalsJac++;
+			jac->assign(4, JRow());
+			auto set = [&](int r, int c0, double v0, int c1, double v1) {
+				JRow& row = (*jac)[r];
+				row.nnz = 2;
+				row.c[0] = c0;
+				row.v[0] = v0;
+				row.c[1] = c1;
+				row.v[1] = v1;
+			};
+			set(0, 0, 1.0, 1, 10.0);
+			set(1, 2, s5, 3, -s5);
+			set(2, 1, d3 + d3, 2, -2.0 * d3 - 2.0 * d3);  // Jet product rule: a v + v a
+			set(3, 0, s10 * d4 + s10 * d4, 3, -(s10 * d4) - s10 * d4);
+		}
+		else
+		{
+			evalsCost++;
+		}
+	}
+};
 
 // feature_detector.cpp:316-414.
 void solveWindow(const Window& w, const orc_solver_opts& o, double* flows,
@@ -1729,6 +1783,47 @@ int orc_interpolate_motion_field(int w, int h, int use_l1, float* field, int n_f
 	if (sum)
 	{
 		*sum = local;
+	}
+	return 0;
+}
+
+// minimize() on Powell's function (see PowellProblem).  opts == NULL: ceres::Solver::Options
+// defaults with max_num_iterations = 100 as in the tutorial.  trace: up to cap rows of
+// {cost, cost_change, gradient max norm, step norm, tr_ratio, tr_radius}, one per accepted step.
+int orc_lm_powell(const orc_solver_opts* opts, double* x, double* trace, int cap, int* n_rows,
+				  orc_summary* sum)
+{
+	if (!x)
+	{
+		return -1;
+	}
+	orc_solver_opts o;
+	if (opts)
+	{
+		o = *opts;
+	}
+	else
+	{
+		orc_default_solver(&o);
+		o.max_num_iterations = 100;
+		o.use_nonmonotonic = 0;
+		o.function_tolerance = 1e-6;
+		o.gradient_tolerance = 1e-10;
+		o.parameter_tolerance = 1e-8;
+	}
+	PowellProblem pb;
+	std::vector<double> rows;
+	g_lmTrace = &rows;
+	minimize(pb, o, x, sum);
+	g_lmTrace = nullptr;
+	const int n = static_cast<int>(rows.size() / 6);
+	if (n_rows)
+	{
+		*n_rows = n;
+	}
+	if (trace)
+	{
+		std::copy(rows.begin(), rows.begin() + 6 * std::min(n, cap), trace);
 	}
 	return 0;
 }

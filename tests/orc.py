@@ -393,3 +393,15 @@ def normalize_nabla(nabla):
     out = np.zeros_like(a)
     assert lib().orc_normalize_nabla(_dp(a), a.size, _dp(out)) == 0
     return out
+
+
+def lm_powell(x0=(3.0, -1.0, 0.0, 1.0), opts=None, cap=200):
+    """oracle.cpp::minimize on Powell's function.  Returns (x, trace [n][6], summary)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    trace = np.zeros((cap, 6))
+    n = C.c_int32()
+    s = Summary()
+    rc = lib().orc_lm_powell(C.byref(opts) if opts is not None else None, _dp(x), _dp(trace), cap,
+                             C.byref(n), C.byref(s))
+    assert rc == 0
+    return x, trace[: n.value].copy(), s

@@ -304,3 +304,23 @@ def test_tv_free_solve_is_chaotic_on_the_cpu_alone(orc, synth):
     assert d50 > 1e-2
     tv50 = np.abs(solve(1e3, s0, 50, 0) - solve(1e3, s1, 50, 0)).max()
     assert tv50 < 1e-9
+
+
+def test_lm_restatement_reproduces_the_table_ceres_publishes(orc):
+    """The trust-region LM the reference delegates to ceres::Solve, as restated in
+    oracle.cpp::minimize (Jacobi scaling 1 / (1 + |column|), LM diagonal clamped and divided by
+    the radius, step quality, radius update, termination tests), run on Powell's function exactly
+    as Ceres' tutorial sets it up, prints the table that tutorial publishes -- every column, every
+    digit, all 14 iterations, the termination reason and the final point."""
+    import json
+    gold = json.load(open(os.path.join(HERE, "golden", "ceres_tutorial_powell.json")))
+    x, trace, s = orc.lm_powell(gold["initial_x"])
+    rows = gold["rows"]
+    assert "%.6e" % s.initial_cost == rows[0][1]
+    assert len(trace) == len(rows) - 1 == s.iterations
+    assert s.termination == 0  # CONVERGENCE, by the gradient tolerance (3.64e-11 <= 1e-10)
+    for got, want in zip(trace, rows[1:]):
+        printed = ["%.6e" % got[0]] + ["%.2e" % v for v in got[1:]]
+        assert printed == want[1:], (want[0], printed, want[1:])
+    assert ["%g" % v for v in x] == gold["final_x_as_printed"]
+    assert "%.6e" % s.final_cost == rows[-1][1]
