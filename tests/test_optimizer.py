@@ -304,3 +304,28 @@ def test_device_solve_edge_cases(ebo, orc):
             c.optimizer_solve([(40.0, 40.0, 0.5, 25.0)], [np.zeros(0)], [p0], [0.5])
     finally:
         c.close()
+
+
+def test_interpolator_reproduces_quadratics_exactly(orc):
+    """Cubic convolution with the Catmull-Rom kernel (Keys 1981, a = -1/2; what
+    ceres::CubicHermiteSpline / BiCubicInterpolator implement) is exact for polynomials up to
+    degree 2 away from the clamped border.  The restated coefficients are checked through the
+    functor: identity warp, flow direction 0 (resp. pi/2) samples gradX (resp. gradY) at
+    (x + tl.x, y + tl.y); the prediction is recovered from the normalised residual."""
+    h, w = 40, 50
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    fx = 0.3 + 0.05 * xs - 0.02 * ys + 0.004 * xs * xs - 0.003 * xs * ys + 0.002 * ys * ys
+    fy = -1.0 + 0.01 * xs + 0.07 * ys - 0.001 * xs * xs + 0.005 * xs * ys
+    grad = np.stack([fx, fy], axis=-1)
+    rect = (10.37, 8.81, 9.0, 7.0)  # fractional corner: every sample is off the grid
+    zero = np.zeros((7, 9))
+    for flow, coef in ((0.0, (0.3, 0.05, -0.02, 0.004, -0.003, 0.002)),
+                       (np.pi / 2, (-1.0, 0.01, 0.07, -0.001, 0.005, 0.0))):
+        q, _, _ = orc.optimizer_cost(grad, rect, zero, pose_of(0.0, 0.0, 0.0), flow, want_jac=False)
+        sq = float(q @ q)
+        p = q * np.sqrt(1e-5 + 1e-5 * sq / (1.0 - sq))
+        X = np.arange(9)[None, :] + rect[0]
+        Y = np.arange(7)[:, None] + rect[1]
+        a, b, c, d, e, f = coef
+        want = a + b * X + c * Y + d * X * X + e * X * Y + f * Y * Y
+        assert np.abs(p.reshape(7, 9) - want).max() < 1e-9 * np.abs(want).max()
