@@ -437,7 +437,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	L.ec.norm_st = normCoef;
 	L.ec.mean_threshold = 0.0001;
 	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
-	L.ec.reserved = 0;
+	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 1));  // separable tensor filter on the 28 B/pixel layout (see ebo_edge.inc)
 	if (launch_eval_edge(L, c->stream))
 	{
 		return c->hip(hipGetLastError(), "edge eval launch");
