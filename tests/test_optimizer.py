@@ -329,3 +329,38 @@ def test_interpolator_reproduces_quadratics_exactly(orc):
         a, b, c, d, e, f = coef
         want = a + b * X + c * Y + d * X * X + e * X * Y + f * Y * Y
         assert np.abs(p.reshape(7, 9) - want).max() < 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_device_functor_random_sweep(ebo, orc):
+    """120 random patches in one launch: odd and non-square sizes, fractional corners, rotations
+    up to +-pi, translations that push part or all of the patch outside the image."""
+    rng = np.random.default_rng(99)
+    grad = make_scene(w=240, h=180, seed=31)
+    rects, nablas, poses, fds = [], [], [], []
+    for i in range(120):
+        pw, ph = int(rng.integers(3, 41)), int(rng.integers(3, 41))
+        rect = (float(rng.uniform(-10, 230)), float(rng.uniform(-10, 170)), float(pw) + float(rng.uniform(0, 0.9)),
+                float(ph) + float(rng.uniform(0, 0.9)))
+        theta = float(rng.uniform(-np.pi, np.pi)) if i % 3 == 0 else float(rng.uniform(-0.1, 0.1))
+        span = 60.0 if i % 4 == 0 else 2.0
+        t = (float(rng.uniform(-span, span)), float(rng.uniform(-span, span)))
+        rects.append(rect)
+        nablas.append(orc.normalize_nabla(rng.integers(-3, 4, (ph, pw)).astype(np.float64) + 0.25))
+        poses.append(pose_of(theta, *t))
+        fds.append(float(rng.uniform(-7, 7)))
+    c = _ctx(ebo)
+    try:
+        c.optimizer_set_grad(grad[..., 0], grad[..., 1])
+        res, jp, jf = c.optimizer_eval(rects, nablas, poses, fds)
+        res_v, _, _ = c.optimizer_eval(rects, nablas, poses, fds, want_jac=False)
+    finally:
+        c.close()
+    for i in range(len(rects)):
+        ro, jpo, jfo = orc.optimizer_cost(grad, rects[i], nablas[i], poses[i], fds[i])
+        rv, _, _ = orc.optimizer_cost(grad, rects[i], nablas[i], poses[i], fds[i], want_jac=False)
+        assert len(res[i]) == int(rects[i][2]) * int(rects[i][3])
+        assert np.abs(res[i] - ro).max() <= 1e-12 * np.abs(ro).max() + 1e-15, i
+        assert np.abs(res_v[i] - rv).max() <= 1e-12 * np.abs(rv).max() + 1e-15, i
+        assert np.abs(jp[i] - jpo).max() <= 1e-10 * max(np.abs(jpo).max(), 1e-300) + 1e-14, i
+        assert np.abs(jf[i] - jfo).max() <= 1e-10 * max(np.abs(jfo).max(), 1e-300) + 1e-14, i
