@@ -91,3 +91,45 @@ def test_edge_jacobian_at_exact_ties(ebo, orc):
             bad += int(d.any(axis=1).sum())
             total += int(active.sum())
     assert total > 200 and bad <= 0.05 * total, (bad, total)
+
+
+def test_random_tracked_patches_integrate_bit_exact(ebo, orc):
+    """Patch::integrateEvents / integrateMotionCompensatedEvents for 200 random tracked patches in
+    one launch each: fractional rect corners (after updatePatchRect), odd sizes, events in deque
+    order, trajectories with zero / negative / tiny time differences, compensated positions that
+    land exactly on .5 (cv::Point2d -> Point2i rounds half to even)."""
+    rng = np.random.RandomState(5)
+    n = 200
+    evs, offsets, rects, trajs, mids = [], [0], [], [], []
+    for i in range(n):
+        ext = int(rng.randint(2, 16))
+        cx, cy = rng.uniform(20, 200), rng.uniform(20, 150)
+        frac = rng.choice([0.0, 0.5, rng.uniform(0, 1)])
+        rect = (cx - ext + frac, cy - ext - frac, 2 * ext + 1, 2 * ext + 1)
+        m = int(rng.randint(1, 300))
+        t = np.sort(rng.randint(1000, 90000, m))[::-1].copy()  # front = newest
+        x = np.floor(cx + rng.uniform(-ext - 3, ext + 3, m)).astype(np.int32)
+        y = np.floor(cy + rng.uniform(-ext - 3, ext + 3, m)).astype(np.int32)
+        ev = ebo.make_events(x, y, t, np.where(rng.rand(m) < 0.5, 1, -1))
+        evs.append(ev)
+        offsets.append(offsets[-1] + m)
+        rects.append(rect)
+        mid = int(orc.mid_timestamp(int(t[0]), int(t[-1])))
+        kind = i % 5
+        t_pre = mid - int(rng.randint(1, 40000)) if kind != 3 else mid + 5  # kind 3: time test fails
+        t_last = t_pre + (int(rng.randint(1, 60000)) if kind != 4 else 2)
+        step = 0.5 if kind == 1 else rng.uniform(-6, 6)
+        trajs.append((cx, cy, float(t_pre), cx + step, cy - step * 0.5, float(t_last)))
+        mids.append(mid)
+    ev = np.concatenate(evs)
+    with ebo.Context(image_w=240, image_h=180, max_events=len(ev)) as c:
+        imgs, cur, last = c.patch_integrate(ev, offsets, rects)
+        mcs, upd = c.patch_integrate_mc(ev, offsets, rects, trajs, mids)
+    for i in range(n):
+        no, co, lo = orc.patch_integrate(evs[i], rects[i])
+        assert np.array_equal(imgs[i], no) and (cur[i], last[i]) == (co, lo), i
+        tr = trajs[i]
+        mo, uo = orc.patch_integrate_mc(evs[i], rects[i], tr[:3], tr[3:], mids[i])
+        assert bool(upd[i]) == uo, i
+        if uo:
+            assert np.array_equal(mcs[i], mo), i
