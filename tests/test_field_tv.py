@@ -261,3 +261,36 @@ def test_device_field_tv_diagonal_preconditioner_agrees(ebo, orc, monkeypatch):
     diff, frac, ok = ulp_report(out_mg, out_j)
     assert ok and frac <= 1e-3
     assert cg_j > 5 * cg_mg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_device_field_tv_random_sweep(ebo, orc, seed):
+    """Random image sizes (odd, non-multiples of the aggregate size), 2..20 tracked points, both
+    fill modes, with and without the Huber loss."""
+    rng = np.random.default_rng(100 + seed)
+    w, h = int(rng.integers(17, 110)), int(rng.integers(13, 90))
+    npatch = int(rng.integers(2, 21))
+    avg = bool(seed % 2)
+    use_l1 = seed % 4 == 3
+    traj, field_o, fixed_o = make_case(orc, w, h, npatch, 300 + seed, use_average=avg)
+    if len(fixed_o) < 2:
+        pytest.skip("fewer than two fixed points")
+    opts = oo = None
+    if use_l1:
+        opts = ebo.default_solver()
+        opts.use_nonmonotonic = 0
+        opts.function_tolerance, opts.gradient_tolerance, opts.parameter_tolerance = 1e-6, 1e-10, 1e-8
+        opts.max_num_iterations = 5
+        oo = orc.default_solver(use_nonmonotonic=0, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                                parameter_tolerance=1e-8, max_num_iterations=5)
+    field, fixed, out, s, cg = run_device(ebo, orc, w, h, traj, avg, use_l1, opts)
+    assert np.array_equal(field, field_o) and np.array_equal(fixed, fixed_o)
+    ref, so, rc = orc.interpolate_motion_field(field_o, fixed_o, use_l1=use_l1, opts=oo)
+    assert rc == 0 and s.iterations == so.iterations
+    assert s.final_cost == pytest.approx(so.final_cost, rel=1e-8)
+    if use_l1:
+        assert np.abs(out.astype(np.float64) - ref).max() < 1e-5
+    else:
+        diff, frac, ok = ulp_report(out, ref)
+        assert ok and frac <= 2e-3, (diff.max(), frac)
