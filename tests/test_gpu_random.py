@@ -133,3 +133,18 @@ def test_random_tracked_patches_integrate_bit_exact(ebo, orc):
         assert bool(upd[i]) == uo, i
         if uo:
             assert np.array_equal(mcs[i], mo), i
+
+
+@pytest.mark.parametrize("seed,n", [(1, 9000), (2, 15000), (4, 9000), (7, 9000)])
+def test_reference_configuration_solves_on_random_windows(ebo, orc, synth, seed, n):
+    """FeatureDetector::compensateEventsContrast as shipped (240x180, 20x20 patches, edge loss, TV,
+    global LM, 50-iteration cap) on further synthetic windows: same iteration count as the
+    oracle's solver, flows within 1e-5 (observed <= 4e-8)."""
+    ev, _ = synth.make_window(0, window=50 + seed, n_events=n)
+    with ebo.Context(image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE, max_events=n) as c:
+        c.set_window(ev)
+        flows, s = c.solve(ebo.default_solver())
+    fo, _, so = orc.compensate_events_contrast(ev, orc.default_params(loss=0), orc.default_solver(), want_image=False)
+    assert s[0].iterations == so.iterations and s[0].termination == so.termination
+    assert np.abs(flows[0] - fo).max() <= 1e-5
+    assert s[0].final_cost == pytest.approx(so.final_cost, rel=1e-9)
