@@ -488,7 +488,19 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		{
 			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,512]");
 		}
-		const int t = static_cast<int>(env_size("EBO_EVAL_TILES", 1));
+		int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
+		if (t <= 0)
+		{
+			// one workgroup per unit unless that leaves the chip empty AND a unit's image needs
+			// several sequential sub-bands anyway (few, large patches: configs[0], one 240x180
+			// patch = a 720x540 canvas): then split the rows over parallel workgroups
+			t = 1;
+			const long canvas = 9L * c->max_rw * c->max_rh;
+			while (canvas > L.cap_doubles && nUnits * (t + 1) <= 128 && t < 8 && (3 * c->max_rh) / (t + 1) >= 16)  // measured (one 240x180 patch per window): 4-8 tiles best up to ~128 workgroups, 1-2 beyond
+			{
+				++t;
+			}
+		}
 		L.tiles = std::max(1, std::min(t, 64));
 	}
 	if (rc)
