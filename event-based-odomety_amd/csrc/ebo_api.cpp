@@ -75,8 +75,10 @@ struct ebo_ctx
 	bool opt_grid_valid = false;
 	void* d_opt = nullptr;           // scratch of ebo_optimizer_eval / _solve
 	size_t opt_cap = 0;
-	unsigned long long* d_count_ovf = nullptr;  // k_count_bands' overflow list
+	unsigned long long* d_count_ovf = nullptr;  // k_count_bands' overflow list / k_csort_* sorted list
 	size_t count_ovf_cap = 0;
+	unsigned int* d_count_bins = nullptr;       // k_csort_*: counts, starts, cursors per (window, band)
+	size_t count_bins_cap = 0;                  // in bins
 	int32_t* d_stats = nullptr;
 	void* d_scratch = nullptr;  // patch-integrate staging
 	size_t scratch_cap = 0;
@@ -491,14 +493,17 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
 		if (t <= 0)
 		{
-			// one workgroup per unit unless that leaves the chip empty AND a unit's image needs
-			// several sequential sub-bands anyway (few, large patches: configs[0], one 240x180
-			// patch = a 720x540 canvas): then split the rows over parallel workgroups
-			t = 1;
+			// One workgroup per unit, unless a unit's image needs many sequential sub-bands (a
+			// patch as large as the frame, configs[0]: a 720x540 canvas): then its rows are split
+			// over a few parallel workgroups (measured there: 4-8 tiles best for few windows, 2 for
+			// many).  The choice depends on the patch geometry only, NOT on the batch size, so that
+			// a window evaluates bit-identically alone and inside any batch.
 			const long canvas = 9L * c->max_rw * c->max_rh;
-			while (canvas > L.cap_doubles && nUnits * (t + 1) <= 128 && t < 8 && (3 * c->max_rh) / (t + 1) >= 16)  // measured (one 240x180 patch per window): 4-8 tiles best up to ~128 workgroups, 1-2 beyond
+			const long subBands = (canvas + L.cap_doubles - 1) / std::max(L.cap_doubles, 1);
+			t = static_cast<int>(std::min<long>(std::max<long>(subBands / 6, 1), 4));
+			while (t > 1 && (3 * c->max_rh) / t < 16)
 			{
-				++t;
+				--t;
 			}
 		}
 		L.tiles = std::max(1, std::min(t, 64));
@@ -789,7 +794,10 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	L.d_image = d_image;
 	L.c = make_consts(c);
 	L.d_overflow = nullptr;
-	if (L.impl < 0 || L.impl == 2)
+	L.d_sort_bins = nullptr;
+	L.sort_bins_cap = 0;
+	L.d_sorted = nullptr;
+	if (L.impl < 0 || L.impl == 2 || L.impl == 3)
 	{
 		size_t total = 0;
 		for (const WindowInfo& wi : c->windows)
@@ -802,6 +810,7 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 			if (c->d_count_ovf)
 			{
 				hipFree(c->d_count_ovf);
+	hipFree(c->d_count_bins);
 	hipFree(c->d_opt_grid);
 	hipFree(c->d_modes);
 	hipFree(c->d_opt);
@@ -817,6 +826,31 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 			c->count_ovf_cap = cap;
 		}
 		L.d_overflow = c->d_count_ovf;
+		if (mode != EBO_COUNT_INTEGRATED)
+		{
+			// sorted bands: the same buffer holds the 4-byte destination list; bins: at most one
+			// band per image row
+			const size_t bins = static_cast<size_t>(c->n_windows) * c->prm.image_h;
+			if (bins > c->count_bins_cap)
+			{
+				if (c->d_count_bins)
+				{
+					hipFree(c->d_count_bins);
+					c->d_count_bins = nullptr;
+					c->count_bins_cap = 0;
+				}
+				int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_count_bins), (3 * bins + 2) * sizeof(unsigned int)),
+								"hipMalloc count bins");
+				if (rc)
+				{
+					return rc;
+				}
+				c->count_bins_cap = bins;
+			}
+			L.d_sort_bins = c->d_count_bins;
+			L.sort_bins_cap = static_cast<int>(std::min<size_t>(c->count_bins_cap, 1u << 30));
+			L.d_sorted = reinterpret_cast<unsigned int*>(c->d_count_ovf);
+		}
 	}
 	if (launch_count_image(L, c->stream))
 	{

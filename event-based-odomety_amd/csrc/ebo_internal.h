@@ -162,9 +162,12 @@ struct CountLaunch
 	int n_windows;
 	int units_per_window; // P + 1
 	int mode;             // EBO_COUNT_*
-	int impl;             // -1 auto, 0 global int atomics + convert, 1 whole-window LDS bands, 2 patch-row bands
+	int impl;             // -1 auto, 0 global int atomics + convert, 1 whole-window LDS bands, 2 patch-row bands, 3 sorted bands
 	int lds_kb;           // LDS per band workgroup (0 = default of the implementation)
 	unsigned long long* d_overflow;  // impl 2: [1 + total events] count + pixel indices (may be null)
+	unsigned int* d_sort_bins;       // impl 3: [3 * sort_bins_cap + 2] counts, starts, cursors (may be null)
+	int sort_bins_cap;               // bins (windows x bands) the buffer holds
+	unsigned int* d_sorted;          // impl 3: [total events] destination pixels sorted by band
 	uint64_t max_window_events;
 	const void* d_aux;    // flows f64 [Wn][P][2] or field f32 [Wn][H][W][2]
 	int32_t* d_counts;    // [Wn][H][W] scratch, zero on entry, zero on exit

@@ -1,5 +1,6 @@
 """GPU tests of the count-image implementations (0: global int atomics, 1: whole-window LDS
-bands, 2: patch-row LDS bands with an overflow list for events that leave their band): all
+bands, 2: patch-row LDS bands with an overflow list for events that leave their band, 3: events
+sorted by destination band, for the warped images of large sensors): all
 bit-exact against the oracle, on single windows and on batches, for all three modes."""
 import numpy as np
 import pytest
@@ -13,7 +14,7 @@ def _prm(orc, c):
                               patch_h=p.patch_h, scale=p.scale, min_events=p.min_events, loss=1)
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "2", "auto"])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "auto"])
 @pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000), (4, 2, 60000)])
 def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config, n_windows, n_events):
     if impl == "auto":
