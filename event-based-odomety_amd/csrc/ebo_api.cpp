@@ -101,7 +101,13 @@ struct ebo_ctx
 	std::vector<int64_t> unit_tref;
 	std::vector<WindowInfo> windows;
 	std::vector<uint64_t> h_packed;
-	std::vector<double> h_out;
+	// pinned, device-visible staging of one evaluation round (flows in, (r, J0, J1) out, modes):
+	// small rounds let the kernels read and write it directly (no copy packets at all), large
+	// ones copy from/to it at DMA speed
+	double* pin_flows = nullptr;
+	double* pin_out = nullptr;
+	unsigned char* pin_modes = nullptr;
+	size_t pin_cap = 0;
 
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int max_rw = 0, max_rh = 0;
@@ -533,67 +539,109 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const unsigned char* modes = nullptr)
 {
 	const size_t nf = c->n_flows();
-	int rc = c->hip(hipMemcpyAsync(c->d_flows, flows, nf * 2 * sizeof(double),
-								   hipMemcpyHostToDevice, c->stream),
-					"H2D flows");
-	if (rc)
+	int rc = EBO_OK;
+	if (nf > c->pin_cap)
 	{
-		return rc;
-	}
-	if (modes)
-	{
-		if (nf > c->modes_cap)
+		if (c->pin_flows)
 		{
-			if (c->d_modes)
-			{
-				hipFree(c->d_modes);
-				c->d_modes = nullptr;
-				c->modes_cap = 0;
-			}
-			rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_modes), nf), "hipMalloc modes");
-			if (rc)
-			{
-				return rc;
-			}
-			c->modes_cap = nf;
+			(void)hipHostFree(c->pin_flows);
+			(void)hipHostFree(c->pin_out);
+			(void)hipHostFree(c->pin_modes);
+			c->pin_flows = c->pin_out = nullptr;
+			c->pin_modes = nullptr;
+			c->pin_cap = 0;
 		}
-		rc = c->hip(hipMemcpyAsync(c->d_modes, modes, nf, hipMemcpyHostToDevice, c->stream), "H2D modes");
+		hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_flows), nf * 2 * sizeof(double), hipHostMallocDefault);
+		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_out), nf * 3 * sizeof(double), hipHostMallocDefault);
+		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_modes), nf, hipHostMallocDefault);
+		rc = c->hip(e, "hipHostMalloc evaluation staging");
 		if (rc)
 		{
 			return rc;
 		}
-		c->modes_active = c->d_modes;
+		std::memset(c->pin_out, 0, nf * 3 * sizeof(double));
+		c->pin_cap = nf;
 	}
-	rc = run_eval_device(c, c->d_flows, jac != nullptr, c->d_out);
+	// Small rounds (a single window's LM round is 108 flows): the kernels read the flows from
+	// and write the results to the pinned buffers themselves; the round is one launch + one
+	// sync.  Larger rounds move the data with async copies (which really are async from pinned).
+	static const size_t zeroCopyMax = env_size("EBO_ZERO_COPY_MAX", 4096);
+	const bool zeroCopy = nf <= zeroCopyMax;
+	std::memcpy(c->pin_flows, flows, nf * 2 * sizeof(double));
+	const double* dFlows = c->pin_flows;
+	double* dOut = c->pin_out;
+	if (!zeroCopy)
+	{
+		rc = c->hip(hipMemcpyAsync(c->d_flows, c->pin_flows, nf * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream),
+					"H2D flows");
+		if (rc)
+		{
+			return rc;
+		}
+		dFlows = c->d_flows;
+		dOut = c->d_out;
+	}
+	if (modes)
+	{
+		std::memcpy(c->pin_modes, modes, nf);
+		c->modes_active = c->pin_modes;
+		if (!zeroCopy)
+		{
+			if (nf > c->modes_cap)
+			{
+				if (c->d_modes)
+				{
+					hipFree(c->d_modes);
+					c->d_modes = nullptr;
+					c->modes_cap = 0;
+				}
+				rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_modes), nf), "hipMalloc modes");
+				if (rc)
+				{
+					return rc;
+				}
+				c->modes_cap = nf;
+			}
+			rc = c->hip(hipMemcpyAsync(c->d_modes, c->pin_modes, nf, hipMemcpyHostToDevice, c->stream), "H2D modes");
+			if (rc)
+			{
+				return rc;
+			}
+			c->modes_active = c->d_modes;
+		}
+	}
+	rc = run_eval_device(c, dFlows, jac != nullptr, dOut);
 	c->modes_active = nullptr;
 	if (rc)
 	{
 		return rc;
 	}
-	c->h_out.resize(nf * 3);
-	rc = c->hip(hipMemcpyAsync(c->h_out.data(), c->d_out, nf * 3 * sizeof(double),
-							   hipMemcpyDeviceToHost, c->stream),
-				"D2H out");
-	if (rc)
+	if (!zeroCopy)
 	{
-		return rc;
+		rc = c->hip(hipMemcpyAsync(c->pin_out, c->d_out, nf * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream),
+					"D2H out");
+		if (rc)
+		{
+			return rc;
+		}
 	}
 	rc = c->hip(hipStreamSynchronize(c->stream), "sync");
 	if (rc)
 	{
 		return rc;
 	}
+	const double* h_out = c->pin_out;
 	for (size_t i = 0; i < nf; ++i)
 	{
 		if (modes && modes[i] == 0)
 		{
 			continue;
 		}
-		r[i] = c->h_out[3 * i];
+		r[i] = h_out[3 * i];
 		if (jac)
 		{
-			jac[2 * i] = c->h_out[3 * i + 1];
-			jac[2 * i + 1] = c->h_out[3 * i + 2];
+			jac[2 * i] = h_out[3 * i + 1];
+			jac[2 * i + 1] = h_out[3 * i + 2];
 		}
 	}
 	return EBO_OK;
@@ -1302,6 +1350,12 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_units);
 	hipFree(c->d_flows);
 	hipFree(c->d_out);
+	if (c->pin_flows)
+	{
+		(void)hipHostFree(c->pin_flows);
+		(void)hipHostFree(c->pin_out);
+		(void)hipHostFree(c->pin_modes);
+	}
 	hipFree(c->d_partials);
 	hipFree(c->d_counts);
 	hipFree(c->d_count_ovf);
