@@ -862,10 +862,6 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 			if (c->d_count_ovf)
 			{
 				hipFree(c->d_count_ovf);
-	hipFree(c->d_count_bins);
-	hipFree(c->d_opt_grid);
-	hipFree(c->d_modes);
-	hipFree(c->d_opt);
 				c->d_count_ovf = nullptr;
 				c->count_ovf_cap = 0;
 			}
@@ -1363,6 +1359,10 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_partials);
 	hipFree(c->d_counts);
 	hipFree(c->d_count_ovf);
+	hipFree(c->d_count_bins);
+	hipFree(c->d_opt_grid);
+	hipFree(c->d_modes);
+	hipFree(c->d_opt);
 	hipFree(c->d_image);
 	hipFree(c->d_aux);
 	hipFree(c->d_stats);
