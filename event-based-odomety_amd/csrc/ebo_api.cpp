@@ -375,11 +375,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	const size_t aliasPerPx = 2 * sizeof(double) + sizeof(int32_t);
 	const char* layoutEnv = std::getenv("EBO_EDGE_LAYOUT");  // 0 / 1 force a layout (A/B)
 	const bool fitsTwice = headerBytes + canvasPx * aliasPerPx + 64 <= 80 * 1024 - 256;
-	// With fewer workgroups than CUs (one window of the reference configuration: 108) nothing
-	// shares a CU and only the latency of one workgroup counts: the 1024-lane layout finishes a
-	// 60x60 canvas in 48 us against 56 us (value only: 28 against 36).
-	const bool latencyBound = static_cast<long>(L.n_units) * L.flow_sets <= 256;
-	L.alias_lds = layoutEnv ? (std::atoi(layoutEnv) != 0) : ((fitsTwice && !latencyBound) ? 1 : 0);
+	L.alias_lds = layoutEnv ? (std::atoi(layoutEnv) != 0) : (fitsTwice ? 1 : 0);
 	const size_t ldsPerPx = L.alias_lds ? aliasPerPx : bytesPerPx;
 	size_t ldsBytes = std::min<size_t>(env_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
 	// no point in reserving more LDS than the whole canvas needs
@@ -449,7 +445,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	L.ec.norm_st = normCoef;
 	L.ec.mean_threshold = 0.0001;
 	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
-	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 1));  // separable tensor filter on the 28 B/pixel layout (see ebo_edge.inc)
+	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 7));  // forms of the separable tensor filter (see EdgeConsts / ebo_edge.inc)
 	if (launch_eval_edge(L, c->stream))
 	{
 		return c->hip(hipGetLastError(), "edge eval launch");

@@ -112,7 +112,7 @@ struct EdgeConsts
 	double norm_st;        // 1 / (2 pi sigmaST^2)
 	double mean_threshold; // 1e-4 (:159)
 	int ablate;            // timing-only ablation mask (EBO_EDGE_ABLATE): 1 eigen, 2 NMS, 4 reverse, 8 gather, 16 scatter
-	int reserved;
+	int reserved;          // tensor filter forms (EBO_EDGE_SEPARABLE): 1 band buffers on the 28 B layout, 2 register runs on the 20 B layout, 4 register runs on the 28 B layout
 };
 
 struct EdgeLaunch

@@ -2364,7 +2364,8 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 	{
 		return 0;
 	}
-	auto edgeKern = L.alias_lds ? k_eval_edge<true> : k_eval_edge<false>;
+	auto edgeKern = L.alias_lds ? (L.want_jac ? k_eval_edge<true, true> : k_eval_edge<true, false>)
+								: (L.want_jac ? k_eval_edge<false, true> : k_eval_edge<false, false>);
 	if (allow_big_lds(edgeKern, L.lds_bytes))
 	{
 		return -2;
