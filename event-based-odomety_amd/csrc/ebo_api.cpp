@@ -168,6 +168,8 @@ EvalConsts make_consts(const ebo_ctx* c)
 	k.patch_h = c->prm.patch_h;
 	k.npx = c->npx;
 	k.npy = c->npy;
+	k.inv_pw = static_cast<uint32_t>((uint64_t(1) << 32) / static_cast<uint64_t>(std::max(k.patch_w, 2)) + 1);
+	k.inv_ph = static_cast<uint32_t>((uint64_t(1) << 32) / static_cast<uint64_t>(std::max(k.patch_h, 2)) + 1);
 	return k;
 }
 

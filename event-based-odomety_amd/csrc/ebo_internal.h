@@ -59,6 +59,7 @@ struct EvalConsts
 	int32_t image_w, image_h;
 	int32_t patch_w, patch_h;
 	int32_t npx, npy;
+	uint32_t inv_pw, inv_ph; // floor(2^32 / patch_w) + 1 (resp. patch_h): x / patch_w == umulhi(x, inv_pw) for 0 <= x < 2^15, patch_w >= 2
 };
 
 // ceres-style solver options for the device solver (mirror of ebo_solver_opts).

@@ -1168,6 +1168,23 @@ __device__ __forceinline__ bool count_target(uint64_t rec, bool live, int dtWin,
 	return live && nx >= 0 && nx < c.image_w && ny >= 0 && ny < c.image_h;
 }
 
+// The unit of an event from its own coordinates, without walking the unit table: the grid patch
+// that contains it (feature_detector.cpp:332-355: index min(x / pw, npx - 1)), or the stray unit P
+// for an event outside the sensor, whose flow is that of the clamped patch (:436-441).  Division
+// by the (uniform) patch size is one mul_hi: exact for 0 <= x < 2^15 (coordinates are 15-bit).
+__device__ __forceinline__ void event_unit(uint64_t rec, const EvalConsts& c, int& patch, int& unit)
+{
+	int x, y, pos, dt;
+	unpack(rec, x, y, pos, dt);
+	const bool inSensor = static_cast<unsigned>(x) < static_cast<unsigned>(c.image_w) &&
+						  static_cast<unsigned>(y) < static_cast<unsigned>(c.image_h);
+	const unsigned xc = static_cast<unsigned>(max(x, 0)), yc = static_cast<unsigned>(max(y, 0));
+	const int bx = min(static_cast<int>(c.patch_w == 1 ? xc : __umulhi(xc, c.inv_pw)), c.npx - 1);
+	const int by = min(static_cast<int>(c.patch_h == 1 ? yc : __umulhi(yc, c.inv_ph)), c.npy - 1);
+	patch = by * c.npx + bx;
+	unit = inSensor ? patch : c.npx * c.npy;
+}
+
 // The flow of the patch a stray event (outside the sensor) is attributed to in the final
 // loop (:436-441, index clamped at 0: negative indices are undefined there).
 __device__ __forceinline__ void stray_flow(uint64_t rec, const double* __restrict__ windowFlows,
@@ -1222,21 +1239,13 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 	// kInFlight independent 8-byte loads per lane are issued before the first is
 	// consumed: ~64 KiB in flight per CU, enough to cover HBM latency (Little's law).
 	constexpr int kInFlight = 8;
-	// pass 0: the patch units (one flow per unit); pass 1: the stray unit (flow per event)
-	for (int pass = 0; pass < 2; ++pass)
+	// Every event finds its unit (reference time, flow) from its own coordinates: no walk along
+	// the unit table, no branch per event, and the 8 in-flight events of a lane are independent
+	// (the first version tracked the current unit per lane: two dependent loads and a divergent
+	// loop per event).  The window's units, the stray one included, are contiguous in `events`.
 	{
-		int ui = pass == 0 ? 0 : P;
-		const int uLast = pass == 0 ? P - 1 : P;
-		const uint32_t evBegin = wu[ui].ev_off;
-		const uint32_t evEnd = wu[uLast].ev_off + wu[uLast].n_ev;
-		uint32_t uEnd = wu[ui].ev_off + wu[ui].n_ev;
-		int dtWin = wu[ui].dt_win;
-		double m0 = 0.0, m1 = 0.0;
-		if (MODE == 1 && pass == 0)
-		{
-			m0 = windowFlows[2 * ui];
-			m1 = windowFlows[2 * ui + 1];
-		}
+		const uint32_t evBegin = wu[0].ev_off;
+		const uint32_t evEnd = wu[P].ev_off + wu[P].n_ev;
 		for (uint32_t eb = evBegin + threadIdx.x; eb < evEnd; eb += kInFlight * blockDim.x)
 		{
 			uint64_t recs[kInFlight];
@@ -1246,31 +1255,32 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 				const uint32_t ek = eb + k * blockDim.x;
 				recs[k] = (ek < evEnd) ? events[ek] : 0ull;
 			}
+			int dtWin[kInFlight];
+			double m0[kInFlight], m1[kInFlight];
 #pragma unroll
 			for (int k = 0; k < kInFlight; ++k)
 			{
-				const uint32_t e = eb + k * blockDim.x;
-				const bool live = e < evEnd;
-				if (MODE != 0 && live && e >= uEnd)  // events are stored unit by unit: advance
+				dtWin[k] = 0;
+				m0[k] = 0.0;
+				m1[k] = 0.0;
+				if (MODE != 0)
 				{
-					do
-					{
-						++ui;
-						uEnd = wu[ui].ev_off + wu[ui].n_ev;
-					} while (e >= uEnd);
-					dtWin = wu[ui].dt_win;
+					int patch, unit;
+					event_unit(recs[k], c, patch, unit);
+					dtWin[k] = wu[unit].dt_win;
 					if (MODE == 1)
 					{
-						m0 = windowFlows[2 * ui];
-						m1 = windowFlows[2 * ui + 1];
+						m0[k] = windowFlows[2 * patch];
+						m1[k] = windowFlows[2 * patch + 1];
 					}
 				}
-				if (MODE == 1 && pass == 1)
-				{
-					stray_flow(recs[k], windowFlows, c, m0, m1);
-				}
+			}
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const bool live = eb + k * blockDim.x < evEnd;
 				int nx, ny;
-				const bool hit = count_target<MODE>(recs[k], live, dtWin, m0, m1, windowField, c, nx, ny);
+				const bool hit = count_target<MODE>(recs[k], live, dtWin[k], m0[k], m1[k], windowField, c, nx, ny);
 				const int ry = ny - row0;
 				if (hit && ry >= 0 && ry < rows)
 				{
@@ -1528,59 +1538,28 @@ __device__ __forceinline__ void sort_targets(const uint64_t* __restrict__ events
 	const size_t imgSize = static_cast<size_t>(c.image_w) * c.image_h;
 	const double* windowFlows = static_cast<const double*>(aux) + (MODE == 1 ? 2 * static_cast<size_t>(w) * P : 0);
 	const float* windowField = static_cast<const float*>(aux) + (MODE == 2 ? 2 * static_cast<size_t>(w) * imgSize : 0);
-	// the unit holding the lane's first event: units are few (<= 1025), binary search
-	int ui = 0;
-	{
-		const uint32_t first = e0 + threadIdx.x;
-		int lo = 0, hi = unitsPerWindow - 1;
-		while (lo < hi)
-		{
-			const int mid = (lo + hi) >> 1;
-			if (wu[mid].ev_off + wu[mid].n_ev <= first)
-			{
-				lo = mid + 1;
-			}
-			else
-			{
-				hi = mid;
-			}
-		}
-		ui = lo;
-	}
-	uint32_t uEnd = wu[ui].ev_off + wu[ui].n_ev;
+	uint64_t recs[16];
 #pragma unroll
 	for (int k = 0; k < 16; ++k)
 	{
 		const uint32_t e = e0 + threadIdx.x + k * 256;
-		dst[k] = 0xFFFFFFFFu;
-		if (e >= e1)
-		{
-			continue;
-		}
-		while (e >= uEnd && ui + 1 < unitsPerWindow)
-		{
-			++ui;
-			uEnd = wu[ui].ev_off + wu[ui].n_ev;
-		}
-		const uint64_t rec = events[e];
+		recs[k] = e < e1 ? events[e] : 0ull;
+	}
+#pragma unroll
+	for (int k = 0; k < 16; ++k)
+	{
+		const uint32_t e = e0 + threadIdx.x + k * 256;
+		int patch, unit;
+		event_unit(recs[k], c, patch, unit);
 		double m0 = 0.0, m1 = 0.0;
 		if (MODE == 1)
 		{
-			if (ui == P)
-			{
-				stray_flow(rec, windowFlows, c, m0, m1);
-			}
-			else
-			{
-				m0 = windowFlows[2 * ui];
-				m1 = windowFlows[2 * ui + 1];
-			}
+			m0 = windowFlows[2 * patch];
+			m1 = windowFlows[2 * patch + 1];
 		}
 		int nx, ny;
-		if (count_target<MODE>(rec, true, wu[ui].dt_win, m0, m1, windowField, c, nx, ny))
-		{
-			dst[k] = static_cast<unsigned int>(ny * c.image_w + nx);
-		}
+		const bool hit = count_target<MODE>(recs[k], e < e1, wu[unit].dt_win, m0, m1, windowField, c, nx, ny);
+		dst[k] = hit ? static_cast<unsigned int>(ny * c.image_w + nx) : 0xFFFFFFFFu;
 	}
 }
 
