@@ -847,6 +847,7 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	L.d_sort_bins = nullptr;
 	L.sort_bins_cap = 0;
 	L.d_sorted = nullptr;
+	L.sorted_cap = 0;
 	if (L.impl < 0 || L.impl == 2 || L.impl == 3)
 	{
 		size_t total = 0;
@@ -896,6 +897,7 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 			L.d_sort_bins = c->d_count_bins;
 			L.sort_bins_cap = static_cast<int>(std::min<size_t>(c->count_bins_cap, 1u << 30));
 			L.d_sorted = reinterpret_cast<unsigned int*>(c->d_count_ovf);
+			L.sorted_cap = c->count_ovf_cap / sizeof(unsigned long long);  // the buffer holds 8 B per event: two 4 B lists
 		}
 	}
 	if (launch_count_image(L, c->stream))

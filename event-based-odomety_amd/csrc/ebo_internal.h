@@ -168,7 +168,8 @@ struct CountLaunch
 	unsigned long long* d_overflow;  // impl 2: [1 + total events] count + pixel indices (may be null)
 	unsigned int* d_sort_bins;       // impl 3: [3 * sort_bins_cap + 2] counts, starts, cursors (may be null)
 	int sort_bins_cap;               // bins (windows x bands) the buffer holds
-	unsigned int* d_sorted;          // impl 3: [total events] destination pixels sorted by band
+	unsigned int* d_sorted;          // impl 3: [sorted_cap] destination pixels sorted by band, then [sorted_cap] in event order
+	size_t sorted_cap;               // events either half holds
 	uint64_t max_window_events;
 	const void* d_aux;    // flows f64 [Wn][P][2] or field f32 [Wn][H][W][2]
 	int32_t* d_counts;    // [Wn][H][W] scratch, zero on entry, zero on exit

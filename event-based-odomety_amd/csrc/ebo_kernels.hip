@@ -1566,7 +1566,8 @@ __device__ __forceinline__ void sort_targets(const uint64_t* __restrict__ events
 template <int MODE>
 __global__ void __launch_bounds__(256) k_csort_hist(const uint64_t* __restrict__ events, const Unit* __restrict__ units,
 													 int unitsPerWindow, const void* __restrict__ aux, int rowsPerBand,
-													 int bandsPerWindow, unsigned int* __restrict__ sortBins, EvalConsts c)
+													 int bandsPerWindow, unsigned int* __restrict__ sortBins,
+													 unsigned int* __restrict__ dstList, EvalConsts c)
 {
 	extern __shared__ unsigned int hist[];
 	const int w = blockIdx.y;
@@ -1590,6 +1591,13 @@ __global__ void __launch_bounds__(256) k_csort_hist(const uint64_t* __restrict__
 #pragma unroll
 	for (int k = 0; k < 16; ++k)
 	{
+		// the destinations are kept (4 B/event, in event order) so that the scatter pass does
+		// not warp again: the f64 warp arithmetic, not the traffic, is what these passes cost
+		const uint32_t e = e0 + threadIdx.x + k * 256;
+		if (e < e1)
+		{
+			dstList[e] = dst[k];
+		}
 		if (dst[k] != 0xFFFFFFFFu)
 		{
 			atomicAdd(&hist[dst[k] / bandPx], 1u);
@@ -1642,11 +1650,9 @@ __global__ void __launch_bounds__(1024) k_csort_scan(unsigned int* __restrict__ 
 	}
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_csort_scatter(const uint64_t* __restrict__ events,
-														const Unit* __restrict__ units, int unitsPerWindow,
-														const void* __restrict__ aux, int rowsPerBand, int bandsPerWindow,
-														unsigned int* __restrict__ sortBins, int nBins,
+__global__ void __launch_bounds__(256) k_csort_scatter(const Unit* __restrict__ units, int unitsPerWindow,
+														const unsigned int* __restrict__ dstList, int rowsPerBand,
+														int bandsPerWindow, unsigned int* __restrict__ sortBins, int nBins,
 														unsigned int* __restrict__ sorted, EvalConsts c)
 {
 	extern __shared__ unsigned int sortLds[];
@@ -1673,7 +1679,12 @@ __global__ void __launch_bounds__(256) k_csort_scatter(const uint64_t* __restric
 	}
 	__syncthreads();
 	unsigned int dst[16];
-	sort_targets<MODE>(events, wu, unitsPerWindow, aux, w, e0, e1, c, dst);
+#pragma unroll
+	for (int k = 0; k < 16; ++k)
+	{
+		const uint32_t e = e0 + threadIdx.x + k * 256;
+		dst[k] = e < e1 ? dstList[e] : 0xFFFFFFFFu;
+	}
 	const unsigned int bandPx = static_cast<unsigned int>(rowsPerBand) * c.image_w;
 #pragma unroll
 	for (int k = 0; k < 16; ++k)
@@ -2453,28 +2464,21 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			const unsigned chunks = static_cast<unsigned>((L.max_window_events + kSortChunk - 1) / kSortChunk);
 			const dim3 grid(std::max(chunks, 1u), L.n_windows);
 			const size_t ldsHist = static_cast<size_t>(bands) * sizeof(unsigned int);
+			unsigned int* dstList = L.d_sorted + L.sorted_cap;  // second half of the list buffer
 			const size_t ldsScatter = 4 * ldsHist + kSortChunk * (sizeof(unsigned int) + sizeof(unsigned short));
 			if (L.mode == 1)
 			{
 				hipLaunchKernelGGL(k_csort_hist<1>, grid, dim3(256), ldsHist, s, L.d_events, L.d_units, L.units_per_window,
-								   L.d_aux, rowsPerBand, bands, L.d_sort_bins, L.c);
+								   L.d_aux, rowsPerBand, bands, L.d_sort_bins, dstList, L.c);
 			}
 			else
 			{
 				hipLaunchKernelGGL(k_csort_hist<2>, grid, dim3(256), ldsHist, s, L.d_events, L.d_units, L.units_per_window,
-								   L.d_aux, rowsPerBand, bands, L.d_sort_bins, L.c);
+								   L.d_aux, rowsPerBand, bands, L.d_sort_bins, dstList, L.c);
 			}
 			hipLaunchKernelGGL(k_csort_scan, dim3(1), dim3(1024), 0, s, L.d_sort_bins, nBins);
-			if (L.mode == 1)
-			{
-				hipLaunchKernelGGL(k_csort_scatter<1>, grid, dim3(256), ldsScatter, s, L.d_events, L.d_units,
-								   L.units_per_window, L.d_aux, rowsPerBand, bands, L.d_sort_bins, nBins, L.d_sorted, L.c);
-			}
-			else
-			{
-				hipLaunchKernelGGL(k_csort_scatter<2>, grid, dim3(256), ldsScatter, s, L.d_events, L.d_units,
-								   L.units_per_window, L.d_aux, rowsPerBand, bands, L.d_sort_bins, nBins, L.d_sorted, L.c);
-			}
+			hipLaunchKernelGGL(k_csort_scatter, grid, dim3(256), ldsScatter, s, L.d_units, L.units_per_window, dstList,
+							   rowsPerBand, bands, L.d_sort_bins, nBins, L.d_sorted, L.c);
 			hipLaunchKernelGGL(count, dim3(bands, L.n_windows), dim3(512), lds, s, L.d_sort_bins, nBins, L.d_sorted,
 							   rowsPerBand, bands, L.d_image, L.c);
 			return check_launch();
