@@ -1536,6 +1536,13 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	return EBO_OK;
 }
 
+// k_bucket_count's per-chunk histogram (count + min/max time per bucket) has to fit a
+// workgroup's LDS; finer grids are bucketed on the host.
+static bool device_bucketing_fits(const ebo_ctx* c)
+{
+	return static_cast<size_t>(c->P + 1) * (2 * sizeof(long long) + sizeof(int)) + 8 <= kLdsBudget - 1024;
+}
+
 int ebo_set_windows_device(ebo_ctx* c, const ebo_event* d_ev, const size_t* offsets, int n_windows)
 {
 	if (!c)
@@ -1553,6 +1560,12 @@ int ebo_set_windows_device(ebo_ctx* c, const ebo_event* d_ev, const size_t* offs
 	if (offsets[n_windows] - offsets[0] > c->cap_events)
 	{
 		return c->fail(EBO_ERR_ARG, "more events than max_events");
+	}
+	if (!device_bucketing_fits(c))
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED,
+					   "device bucketing keeps one histogram slot per patch in LDS (about 8000 patches); "
+					   "pass host events to ebo_set_windows for finer grids");
 	}
 	return set_windows_on_device(c, d_ev, offsets, n_windows);
 }
@@ -1579,7 +1592,7 @@ int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int 
 		return c->fail(EBO_ERR_ARG, "more events than max_events");
 	}
 	const char* mode = std::getenv("EBO_BUCKET");
-	if (mode && std::strcmp(mode, "host") == 0)
+	if ((mode && std::strcmp(mode, "host") == 0) || !device_bucketing_fits(c))
 	{
 		return set_windows_host(c, ev, offsets, n_windows);
 	}

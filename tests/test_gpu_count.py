@@ -86,3 +86,31 @@ def test_patch_row_bands_any_band_size_and_large_flows(ebo, orc, synth, monkeypa
             sub = ev[int(offsets[k]):int(offsets[k + 1])]
             assert np.array_equal(warped[k], orc.final_count_image(sub, prm, flows[k]))
             assert np.array_equal(integ[k], orc.integrate_events(sub, 240, 180))
+
+
+@pytest.mark.parametrize("impl", ["1", "3"])
+@pytest.mark.parametrize("image,patch", [((16383, 24), (2, 24)), ((16383, 24), (3, 5)), ((16000, 20), (127, 1)),
+                                         ((9000, 30), (8999, 7)), ((40, 16383), (1, 16383)), ((64, 48), (1, 1))])
+def test_patch_of_an_event_from_its_coordinates(ebo, orc, monkeypatch, impl, image, patch):
+    """The warped-count kernels find an event's patch as min(x / patch_w, npx - 1) with one
+    multiply-high by a precomputed reciprocal: exact over the whole 15-bit coordinate range, for
+    divisors from 1 to the sensor size, ragged last patches, and events outside the sensor (which
+    take the flow of the clamped patch)."""
+    monkeypatch.setenv("EBO_COUNT_IMPL", impl)
+    w, h = image
+    rng = np.random.RandomState(w + patch[0])
+    n = 6000
+    x = rng.randint(0, w, n).astype(np.int32)
+    y = rng.randint(0, h, n).astype(np.int32)
+    # both sides of every patch boundary near the ends, the last pixel, and a few strays
+    x[:8] = [0, patch[0] - 1, min(patch[0], w - 1), w - 1, w - 2, max(w - patch[0], 0), -3, min(w + 2, 16383)]
+    y[:8] = [0, patch[1] - 1, min(patch[1], h - 1), h - 1, h - 2, max(h - patch[1], 0), 2, min(h + 1, 16383)]
+    t = np.sort(rng.randint(0, 40000, n)) + 10_000
+    ev = ebo.make_events(x, y, t, np.ones(n, dtype=np.int32))
+    with ebo.Context(image_w=w, image_h=h, patch_w=patch[0], patch_h=patch[1], loss=ebo.LOSS_VARIANCE,
+                     tv_weight=0.0, max_events=n) as c:
+        c.set_window(ev)
+        prm = _prm(orc, c)
+        flows = rng.uniform(-1.5, 1.5, (c.P, 2))
+        warped = c.count_image(ebo.COUNT_WARPED, flows)[0]
+        assert np.array_equal(warped, orc.final_count_image(ev, prm, flows))
