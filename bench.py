@@ -197,7 +197,7 @@ def main():
     extras = {}
     if cpu_all is not None:
         extras["cpu_baseline_all_cores"] = cpu_all
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:  # single-GPU diagnostics; ranks of an N > 1 run stay in step
         # value-only evaluation (the cost-only evaluations of the LM loop)
         torch.cuda.synchronize()
         e0.record(stream)
