@@ -104,6 +104,8 @@ struct ebo_ctx
 	// pinned, device-visible staging of one evaluation round (flows in, (r, J0, J1) out, modes):
 	// small rounds let the kernels read and write it directly (no copy packets at all), large
 	// ones copy from/to it at DMA speed
+	void* pin_bucket = nullptr;      // pinned mirror of the bucketing results (offsets in; units, reference times, flag out)
+	size_t pin_bucket_cap = 0;
 	double* pin_flows = nullptr;
 	double* pin_out = nullptr;
 	unsigned char* pin_modes = nullptr;
@@ -1356,6 +1358,10 @@ void ebo_destroy(ebo_ctx* c)
 		(void)hipHostFree(c->pin_out);
 		(void)hipHostFree(c->pin_modes);
 	}
+	if (c->pin_bucket)
+	{
+		(void)hipHostFree(c->pin_bucket);
+	}
 	hipFree(c->d_partials);
 	hipFree(c->d_counts);
 	hipFree(c->d_count_ovf);
@@ -1485,7 +1491,30 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	L.d_units = c->d_units;
 	L.d_packed = c->d_events;
 	L.c = make_consts(c);
-	int rc = c->hip(hipMemcpyAsync(const_cast<unsigned long long*>(L.d_offsets), off64.data(), off64.size() * 8,
+	// pinned mirror: offsets go up and (units | unit tref, window tref, flag) come back as three
+	// truly asynchronous copies and ONE synchronisation (copies from/to pageable memory are
+	// staged one by one by the runtime: 0.176 -> 0.131 ms for a 15 k-event window)
+	const size_t tail = bT + bW + 256;  // unit tref | window tref | flag, contiguous in the scratch block
+	const size_t pUnits = al(nUnits * sizeof(Unit));
+	const size_t pinNeed = bOff + pUnits + tail;
+	if (pinNeed > c->pin_bucket_cap)
+	{
+		if (c->pin_bucket)
+		{
+			(void)hipHostFree(c->pin_bucket);
+			c->pin_bucket = nullptr;
+			c->pin_bucket_cap = 0;
+		}
+		int rcp = c->hip(hipHostMalloc(&c->pin_bucket, pinNeed, hipHostMallocDefault), "hipHostMalloc bucket mirror");
+		if (rcp)
+		{
+			return rcp;
+		}
+		c->pin_bucket_cap = pinNeed;
+	}
+	char* pin = static_cast<char*>(c->pin_bucket);
+	std::memcpy(pin, off64.data(), off64.size() * 8);
+	int rc = c->hip(hipMemcpyAsync(const_cast<unsigned long long*>(L.d_offsets), pin, off64.size() * 8,
 								   hipMemcpyHostToDevice, c->stream),
 					"H2D offsets");
 	if (rc)
@@ -1496,20 +1525,22 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	{
 		return c->hip(hipGetLastError(), "bucket launch");
 	}
-	std::vector<Unit> units(nUnits);
-	std::vector<int64_t> utref(nUnits);
-	std::vector<long long> wtref(n_windows);
-	int flag = 0;
-	hipError_t e = hipMemcpyAsync(units.data(), c->d_units, nUnits * sizeof(Unit), hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(utref.data(), L.d_unit_tref, nUnits * 8, hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(wtref.data(), L.d_win_tref, n_windows * 8, hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(&flag, L.d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+	hipError_t e = hipMemcpyAsync(pin + bOff, c->d_units, nUnits * sizeof(Unit), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(pin + bOff + pUnits, L.d_unit_tref, tail, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e != hipSuccess)
 	{
 		c->n_windows = 0;
 		return c->hip(e, "bucket results");
 	}
+	std::vector<Unit> units(nUnits);
+	std::vector<int64_t> utref(nUnits);
+	std::vector<long long> wtref(n_windows);
+	int flag = 0;
+	std::memcpy(units.data(), pin + bOff, nUnits * sizeof(Unit));
+	std::memcpy(utref.data(), pin + bOff + pUnits, nUnits * 8);
+	std::memcpy(wtref.data(), pin + bOff + pUnits + bT, n_windows * 8);
+	std::memcpy(&flag, pin + bOff + pUnits + bT + bW, sizeof(int));
 	if (flag)
 	{
 		c->n_windows = 0;
