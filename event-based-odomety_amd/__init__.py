@@ -504,6 +504,24 @@ class Context:
                 for i in range(n)]
         return imgs, upd
 
+    # -- event -> tracked-patch routing (FeatureDetector::updatePatches) --------
+    def route_set_events(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self._check(lib().ebo_route_set_events(self._h, _vp(ev), C.c_size_t(len(ev))))
+
+    def route_events(self, rects, start, max_take, cap):
+        """-> (list of index arrays per patch, next index per patch)."""
+        rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        n = len(rects)
+        start = np.ascontiguousarray(start, dtype=np.uint32)
+        max_take = np.ascontiguousarray(max_take, dtype=np.uint32)
+        idx = np.zeros((n, max(int(cap), 1)), dtype=np.uint32)
+        cnt = np.zeros(n, dtype=np.uint32)
+        nxt = np.zeros(n, dtype=np.uint32)
+        self._check(lib().ebo_route_events(self._h, n, _dp(rects), _vp(start), _vp(max_take), C.c_uint32(int(cap)),
+                                           _vp(idx), _vp(cnt), _vp(nxt)))
+        return [idx[i, :cnt[i]].copy() for i in range(n)], nxt
+
     # -- RCCL exchange (no framework) -----------------------------------------
     def comm_init(self, comm_id, rank, nranks):
         buf = (C.c_char * 128).from_buffer_copy(bytes(comm_id))

@@ -104,6 +104,11 @@ struct ebo_ctx
 	// pinned, device-visible staging of one evaluation round (flows in, (r, J0, J1) out, modes):
 	// small rounds let the kernels read and write it directly (no copy packets at all), large
 	// ones copy from/to it at DMA speed
+	uint32_t* d_route_xy = nullptr;  // ebo_route_set_events: x:16 | y:16 per event of the chunk
+	size_t route_cap = 0;
+	size_t route_n = 0;
+	void* pin_route = nullptr;       // pinned, device-visible arguments and results of ebo_route_events
+	size_t pin_route_cap = 0;
 	void* pin_bucket = nullptr;      // pinned mirror of the bucketing results (offsets in; units, reference times, flag out)
 	size_t pin_bucket_cap = 0;
 	double* pin_flows = nullptr;
@@ -1362,6 +1367,11 @@ void ebo_destroy(ebo_ctx* c)
 	{
 		(void)hipHostFree(c->pin_bucket);
 	}
+	if (c->pin_route)
+	{
+		(void)hipHostFree(c->pin_route);
+	}
+	hipFree(c->d_route_xy);
 	hipFree(c->d_partials);
 	hipFree(c->d_counts);
 	hipFree(c->d_count_ovf);
@@ -2359,6 +2369,122 @@ static int patch_integrate_common(ebo_ctx* c, const ebo_event* ev, const size_t*
 		return rc;
 	}
 	return c->hip(hipStreamSynchronize(c->stream), "sync");
+}
+
+int ebo_route_set_events(ebo_ctx* c, const ebo_event* ev, size_t n)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if ((!ev && n > 0) || n > 0xFFFFFFF0u)
+	{
+		return c->fail(EBO_ERR_ARG, "null events or more than 2^32 events in a chunk");
+	}
+	(void)hipSetDevice(c->prm.device);
+	c->route_n = 0;
+	if (n > c->route_cap)
+	{
+		hipFree(c->d_route_xy);
+		c->d_route_xy = nullptr;
+		c->route_cap = 0;
+		int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_route_xy), n * sizeof(uint32_t)), "hipMalloc route events");
+		if (rc)
+		{
+			return rc;
+		}
+		c->route_cap = n;
+	}
+	std::vector<uint32_t> xy(n);
+	for (size_t i = 0; i < n; ++i)
+	{
+		if (ev[i].x < kCoordMin || ev[i].x > kCoordMax || ev[i].y < kCoordMin || ev[i].y > kCoordMax)
+		{
+			return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
+		}
+		xy[i] = (static_cast<uint32_t>(ev[i].x) & 0xFFFFu) | (static_cast<uint32_t>(ev[i].y) << 16);
+	}
+	if (n > 0)
+	{
+		int rc = c->hip(hipMemcpy(c->d_route_xy, xy.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D route events");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	c->route_n = n;
+	return EBO_OK;
+}
+
+int ebo_route_events(ebo_ctx* c, int n_patches, const double* rects, const uint32_t* start, const uint32_t* max_take,
+					 uint32_t cap, uint32_t* out_index, uint32_t* out_count, uint32_t* out_next)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (n_patches < 0 || (n_patches > 0 && (!rects || !start || !max_take || !out_count || !out_next)) ||
+		(cap > 0 && n_patches > 0 && !out_index))
+	{
+		return c->fail(EBO_ERR_ARG, "null argument");
+	}
+	if (n_patches == 0)
+	{
+		return EBO_OK;
+	}
+	(void)hipSetDevice(c->prm.device);
+	// one pinned block the kernel reads its arguments from and writes its results to (all small:
+	// no copy packets, one launch + one sync): rects | start | take | count | next | index
+	const size_t np = static_cast<size_t>(n_patches);
+	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+	const size_t bR = al(np * 32), bU = al(np * 4), bI = al(np * cap * 4 + 4);
+	const size_t need = bR + 4 * bU + bI;
+	if (need > c->pin_route_cap)
+	{
+		if (c->pin_route)
+		{
+			(void)hipHostFree(c->pin_route);
+			c->pin_route = nullptr;
+			c->pin_route_cap = 0;
+		}
+		int rc = c->hip(hipHostMalloc(&c->pin_route, need, hipHostMallocDefault), "hipHostMalloc route staging");
+		if (rc)
+		{
+			return rc;
+		}
+		c->pin_route_cap = need;
+	}
+	char* pin = static_cast<char*>(c->pin_route);
+	std::memcpy(pin, rects, np * 32);
+	std::memcpy(pin + bR, start, np * 4);
+	std::memcpy(pin + bR + bU, max_take, np * 4);
+	RouteLaunch L;
+	L.d_xy = c->d_route_xy;
+	L.n_events = static_cast<uint32_t>(c->route_n);
+	L.n_patches = n_patches;
+	L.d_rects = reinterpret_cast<const double*>(pin);
+	L.d_start = reinterpret_cast<const uint32_t*>(pin + bR);
+	L.d_take = reinterpret_cast<const uint32_t*>(pin + bR + bU);
+	L.d_count = reinterpret_cast<uint32_t*>(pin + bR + 2 * bU);
+	L.d_next = reinterpret_cast<uint32_t*>(pin + bR + 3 * bU);
+	L.d_index = reinterpret_cast<uint32_t*>(pin + bR + 4 * bU);
+	L.cap = cap;
+	if (launch_route(L, c->stream))
+	{
+		return c->hip(hipGetLastError(), "route launch");
+	}
+	int rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	if (rc)
+	{
+		return rc;
+	}
+	std::memcpy(out_count, L.d_count, np * 4);
+	std::memcpy(out_next, L.d_next, np * 4);
+	for (size_t p = 0; p < np; ++p)
+	{
+		std::memcpy(out_index + p * cap, L.d_index + p * cap, static_cast<size_t>(out_count[p]) * 4);
+	}
+	return EBO_OK;
 }
 
 int ebo_patch_integrate(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_patches,

@@ -317,4 +317,20 @@ struct PatchIntLaunch
 };
 int launch_patch_integrate(const PatchIntLaunch& L, void* stream);
 
+// Event -> tracked-patch routing (FeatureDetector::updatePatches): one wave per patch.
+struct RouteLaunch
+{
+	const uint32_t* d_xy;      // [n_events] x:16 | y:16 (two's complement halves)
+	uint32_t n_events;
+	int n_patches;
+	const double* d_rects;     // [n][4]
+	const uint32_t* d_start;   // [n]
+	const uint32_t* d_take;    // [n]
+	uint32_t cap;
+	uint32_t* d_index;         // [n][cap]
+	uint32_t* d_count;         // [n]
+	uint32_t* d_next;          // [n]
+};
+int launch_route(const RouteLaunch& L, void* stream);
+
 }  // namespace ebo

@@ -1886,6 +1886,67 @@ __global__ void k_patch_integrate(const uint64_t* __restrict__ events,
 	}
 }
 
+// FeatureDetector::updatePatches' routing test for a chunk of the stream (feature_detector.cpp:
+// 589-596, cv::Rect2d::contains on the integer point): one wave per tracked patch walks the
+// chunk from start[p], 256 events per step (four coalesced 256-byte loads), compacts the indices
+// of the events inside the rect with ballots -- no barriers, no atomics, stream order kept -- and
+// stops at the event that fills the patch's quota.
+__global__ void __launch_bounds__(64) k_route(const uint32_t* __restrict__ xy, uint32_t nEvents,
+											  const double* __restrict__ rects, const uint32_t* __restrict__ start,
+											  const uint32_t* __restrict__ take, uint32_t cap,
+											  uint32_t* __restrict__ outIndex, uint32_t* __restrict__ outCount,
+											  uint32_t* __restrict__ outNext)
+{
+	const int p = blockIdx.x;
+	const double rx = rects[4 * p + 0], ry = rects[4 * p + 1];
+	const double rx1 = rx + rects[4 * p + 2], ry1 = ry + rects[4 * p + 3];
+	const uint32_t quota = min(take[p], cap);
+	uint32_t* out = outIndex + static_cast<size_t>(p) * cap;
+	const int lane = threadIdx.x;
+	uint32_t taken = 0;
+	uint32_t next = nEvents;
+	for (uint32_t base = start[p]; base < nEvents && taken < quota; base += 256)
+	{
+		uint32_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const uint32_t e = base + k * 64 + lane;
+			v[k] = e < nEvents ? xy[e] : 0u;
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const uint32_t e = base + k * 64 + lane;
+			const double px = static_cast<double>(static_cast<int>(static_cast<int16_t>(v[k] & 0xFFFFu)));
+			const double py = static_cast<double>(static_cast<int>(static_cast<int16_t>(v[k] >> 16)));
+			const bool in = e < nEvents && rx <= px && px < rx1 && ry <= py && py < ry1;
+			const unsigned long long m = __ballot(in);
+			const uint32_t rank = taken + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+			if (in && rank < quota)
+			{
+				out[rank] = e;
+				if (rank + 1 == quota)
+				{
+					next = e + 1;  // exactly one lane of the whole walk
+				}
+			}
+			taken += static_cast<uint32_t>(__popcll(m));
+		}
+	}
+	// `next` lives in the lane that took the last event: publish it to the wave
+	const unsigned long long who = __ballot(next != nEvents);
+	if (who)
+	{
+		next = __shfl(next, __ffsll(static_cast<long long>(who)) - 1);
+	}
+	if (lane == 0)
+	{
+		outCount[p] = min(taken, quota);
+		outNext[p] = (quota == 0) ? start[p] : next;
+	}
+}
+
 #include "ebo_edge.inc"
 #include "ebo_bucket.inc"
 #include "ebo_field.inc"
@@ -2531,6 +2592,17 @@ int launch_count_image(const CountLaunch& L, void* stream)
 	}
 	const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 2048));
 	hipLaunchKernelGGL(k_counts_to_f64, dim3(blocks), dim3(256), 0, s, L.d_counts, L.d_image, n);
+	return check_launch();
+}
+
+int launch_route(const RouteLaunch& L, void* stream)
+{
+	if (L.n_patches == 0)
+	{
+		return 0;
+	}
+	hipLaunchKernelGGL(k_route, dim3(L.n_patches), dim3(64), 0, static_cast<hipStream_t>(stream), L.d_xy, L.n_events,
+					   L.d_rects, L.d_start, L.d_take, L.cap, L.d_index, L.d_count, L.d_next);
 	return check_launch();
 }
 

@@ -274,6 +274,23 @@ int ebo_optimizer_eval(ebo_ctx* ctx, int n, const double* rects, const double* n
 int ebo_optimizer_solve(ebo_ctx* ctx, int n, const double* rects, const double* nabla, int normalize, double huber,
 						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries);
 
+/* Event -> tracked-patch routing: what FeatureDetector::updatePatches does per event,
+ * `if (patch.isInPatch(event.value.point)) patch.addEvent(event)` (feature_detector.cpp:585-596;
+ * cv::Rect2d::contains on the integer point: x <= px < x + w, y <= py < y + h in double), for a
+ * whole chunk of the stream and all tracked patches in one launch instead of one host test per
+ * (event, patch).  ebo_route_set_events keeps the chunk's coordinates on the device (4 B/event);
+ * ebo_route_events then gives, for patch i with rect rects[i][4], the indices (ascending = stream
+ * order) of the first max_take[i] events at or after start[i] that fall inside it:
+ * out_index[i * cap + k], k < out_count[i] <= min(max_take[i], cap), and out_next[i] = index after
+ * the last event taken when the quota was reached, else n (chunk exhausted).  A patch's rect moves
+ * when it is optimised, so a caller routes up to the event that makes a patch ready, optimises,
+ * and routes again from out_next with the new rect (tracker::FeatureDetector::updatePatches(chunk)
+ * in the facade does exactly that, all patches in lock step). */
+int ebo_route_set_events(ebo_ctx* ctx, const ebo_event* ev, size_t n);
+int ebo_route_events(ebo_ctx* ctx, int n_patches, const double* rects, const uint32_t* start,
+					 const uint32_t* max_take, uint32_t cap, uint32_t* out_index, uint32_t* out_count,
+					 uint32_t* out_next);
+
 /* R2 in one call: set window, solve, final warped count image.
  * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */
 int ebo_compensate_events_contrast(ebo_ctx* ctx, const ebo_event* ev, size_t n,

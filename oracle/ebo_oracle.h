@@ -239,6 +239,10 @@ int orc_patch_integrate(const orc_event* ev, size_t n, double rx, double ry,
 /* Patch::integrateMotionCompensatedEvents (patch.cpp:87-130).
  * traj: last two trajectory samples {x,y,t_us} (prelast, last). Returns 1 in
  * *updated if the image was rebuilt. */
+/* FeatureDetector::updatePatches' event -> patch routing (feature_detector.cpp:585-596). */
+int orc_route_events(const orc_event* ev, size_t n, int n_patches, const double* rects,
+					 const uint32_t* start, const uint32_t* max_take, uint32_t cap, uint32_t* out_index,
+					 uint32_t* out_count, uint32_t* out_next);
 int orc_patch_integrate_mc(const orc_event* ev, size_t n, double rx, double ry,
 						   double rw, double rh, const double* prelast_xy,
 						   int64_t prelast_t, const double* last_xy,

@@ -1863,6 +1863,47 @@ int orc_patch_integrate(const orc_event* ev, size_t n, double rx, double ry,
 	return 0;
 }
 
+// FeatureDetector::updatePatches' routing (feature_detector.cpp:585-596): events in stream
+// order (outer loop), patches inner, `if (patch.isInPatch(event.value.point)) patch.addEvent`;
+// isInPatch = cv::Rect2d::contains(Point2i) (patch.cpp:172-175).  A patch starts listening at
+// start[p] and stops after max_take[p] events (the caller optimises it then and its rect moves).
+int orc_route_events(const orc_event* ev, size_t n, int n_patches, const double* rects,
+					 const uint32_t* start, const uint32_t* max_take, uint32_t cap, uint32_t* out_index,
+					 uint32_t* out_count, uint32_t* out_next)
+{
+	if ((!ev && n) || n_patches < 0 || !rects || !start || !max_take || !out_count || !out_next)
+	{
+		return -1;
+	}
+	for (int p = 0; p < n_patches; ++p)
+	{
+		out_count[p] = 0;
+		out_next[p] = (std::min(max_take[p], cap) == 0) ? start[p] : static_cast<uint32_t>(n);
+	}
+	for (size_t e = 0; e < n; ++e)
+	{
+		for (int p = 0; p < n_patches; ++p)
+		{
+			const uint32_t quota = std::min(max_take[p], cap);
+			if (e < start[p] || out_count[p] >= quota)
+			{
+				continue;
+			}
+			const double rx = rects[4 * p], ry = rects[4 * p + 1], rw = rects[4 * p + 2], rh = rects[4 * p + 3];
+			const double x = ev[e].x, y = ev[e].y;
+			if (rx <= x && x < rx + rw && ry <= y && y < ry + rh)
+			{
+				out_index[static_cast<size_t>(p) * cap + out_count[p]] = static_cast<uint32_t>(e);
+				if (++out_count[p] == quota)
+				{
+					out_next[p] = static_cast<uint32_t>(e + 1);
+				}
+			}
+		}
+	}
+	return 0;
+}
+
 // patch.cpp:87-130.  Point2d -> Point2i is cv::saturate_cast<int>(double) =
 // cvRound = round half to even under the default rounding mode (F7).
 int orc_patch_integrate_mc(const orc_event* ev, size_t n, double rx, double ry,

@@ -270,6 +270,24 @@ def patch_integrate(ev, rect):
     return nabla, cur.value, last.value
 
 
+def route_events(ev, rects, start, max_take, cap):
+    """FeatureDetector::updatePatches' routing loop -> (index arrays per patch, next per patch)."""
+    ev, p = _evp(ev)
+    rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+    n = len(rects)
+    start = np.ascontiguousarray(start, dtype=np.uint32)
+    max_take = np.ascontiguousarray(max_take, dtype=np.uint32)
+    idx = np.zeros((n, max(int(cap), 1)), dtype=np.uint32)
+    cnt = np.zeros(n, dtype=np.uint32)
+    nxt = np.zeros(n, dtype=np.uint32)
+    rc = lib().orc_route_events(p, C.c_size_t(len(ev)), n, _dp(rects), start.ctypes.data_as(C.c_void_p),
+                                max_take.ctypes.data_as(C.c_void_p), C.c_uint32(int(cap)),
+                                idx.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+                                nxt.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return [idx[i, :cnt[i]].copy() for i in range(n)], nxt
+
+
 def patch_integrate_mc(ev, rect, prelast, last, mid_time):
     """Patch::integrateMotionCompensatedEvents; prelast/last = (x, y, t_us)."""
     ev, p = _evp(ev)
