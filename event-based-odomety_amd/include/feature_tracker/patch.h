@@ -86,6 +86,14 @@ class Patch
 	Corner toCorner() const { return Corner(patch_.x + (patch_.width - 1) / 2., patch_.y + (patch_.height - 1) / 2.); }
 	bool isInPatch(const common::Point2i& point) const { return patch_.contains(point); }
 	bool isReady() const { return counter_ >= 30 && events_.size() >= numOfEvents_; }
+	// how many more addEvent calls until isReady() (0: ready now); what a batched caller asks
+	// the device router for
+	size_t eventsUntilReady() const
+	{
+		const size_t byCounter = counter_ >= 30 ? 0 : 30 - counter_;
+		const size_t bySize = events_.size() >= numOfEvents_ ? 0 : numOfEvents_ - events_.size();
+		return std::max(byCounter, bySize);
+	}
 	bool isLost() const { return lost_; }
 	bool isInit() const { return init_; }
 

@@ -1,0 +1,268 @@
+// feature_tracker/tracked_patches.h — the tracked-patch half of tracker::FeatureDetector with
+// the reference's names: `patches_`, `optimizers_`, `updatePatches`, `updateNumOfEvents`
+// (implementation/feature_tracker/src/feature_detector.cpp:585-619,666-711; members
+// feature_detector.h:100-118).  A class of its own here only because of header layering
+// (tracker::Patch needs Mat64 from feature_detector.h); a FeatureDetector owns one.
+//
+//   updatePatches(const common::EventSample&)        the reference's per-event call, verbatim order:
+//        for every patch that is not lost: addEvent if the event is inside its rect; then, if the
+//        patch isReady() && isInit(): optimizers_[initTime]->optimize(patch); updateNumOfEvents.
+//   updatePatches(const std::vector<EventSample>&)   the same for a whole chunk of the stream, the
+//        way the device wants it.  Patches do not interact (a patch's events, readiness and
+//        optimisation depend on its own state only), so all patches advance in lock-step ROUNDS:
+//        one ebo_route_events launch finds, for every patch, the events inside its current rect up
+//        to the one that makes it ready (events -> patches, all at once, instead of one host test
+//        per (event, patch)); the patches that became ready are optimised together (one launch
+//        per stage, Optimizer::optimize(std::vector<Patch*>)); their rects have moved, so the next
+//        round routes the rest of the chunk from where each patch stopped.  Per patch the sequence
+//        of addEvent / optimize calls is exactly the per-event one.
+//
+// Not built: the event-count estimate of updateNumOfEvents (:689-707), which warps the whole
+// gradient images with cv::warpAffine (OpenCV's fixed-point bilinear tables) and sums them over
+// the rect; its two border branches (:668-687) are.  A caller with OpenCV plugs the estimate in
+// with setNumOfEventsEstimator; without one a patch keeps its event count.  Patch::warpImage
+// (a visualisation, :615) is not built.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "optimizer.h"
+#include "patch.h"
+
+namespace tracker
+{
+using Patches = std::vector<Patch>;
+
+class TrackedPatches
+{
+   public:
+	// imageSize = gradX_.size() of the reference; initNumEvents = DetectorParams::initNumEvents
+	TrackedPatches(const Size& imageSize, int initNumEvents = 75, int device = 0)
+		: imageSize_(imageSize), initNumEvents_(initNumEvents)
+	{
+		ebo_params p;
+		ebo_default_params(&p);
+		p.device = device;
+		p.image_w = imageSize.width;
+		p.image_h = imageSize.height;
+		if (ebo_create(&p, &ctx_) != EBO_OK)
+		{
+			throw std::runtime_error(std::string("tracker::TrackedPatches: ") + ebo_last_error(nullptr));
+		}
+	}
+	~TrackedPatches() { ebo_destroy(ctx_); }
+	TrackedPatches(const TrackedPatches&) = delete;
+	TrackedPatches& operator=(const TrackedPatches&) = delete;
+
+	Patches& getPatches() { return patches_; }
+	Patches const& getPatches() const { return patches_; }
+	void addPatch(const Patch& patch) { patches_.push_back(patch); }
+
+	// optimizers_[image.timestamp.count()] of the reference (:560-563): the optimizer holding the
+	// gradient grid of the image a patch was extracted from, keyed by the patch's init time
+	void setOptimizer(const common::timestamp_t& initTime, std::shared_ptr<Optimizer> optimizer)
+	{
+		optimizers_[initTime.count()] = std::move(optimizer);
+	}
+	void setNumOfEventsEstimator(std::function<size_t(const Patch&)> estimator) { estimator_ = std::move(estimator); }
+
+	// feature_detector.cpp:666-711
+	void updateNumOfEvents(Patch& patch)
+	{
+		const Rect2d& rect = patch.getPatch();
+		// (rect.tl() + rect.br()) * 0.5
+		const double cx = (rect.x + (rect.x + rect.width)) * 0.5, cy = (rect.y + (rect.y + rect.height)) * 0.5;
+		if (cx <= 5 || cy <= 5 || cx >= imageSize_.width - 5 || cy >= imageSize_.height - 5)
+		{
+			patch.setLost();
+			return;
+		}
+		if (rect.x < 0 || rect.y < 0 || rect.x + rect.width >= imageSize_.width ||
+			rect.y + rect.height >= imageSize_.height)
+		{
+			patch.setNumOfEvents(static_cast<size_t>(initNumEvents_));
+			return;
+		}
+		if (estimator_)
+		{
+			patch.setNumOfEvents(estimator_(patch));
+		}
+	}
+
+	// feature_detector.cpp:585-619, one event
+	void updatePatches(const common::EventSample& event)
+	{
+		for (auto& patch : patches_)
+		{
+			if (!patch.isLost())
+			{
+				if (patch.isInPatch(event.value.point))
+				{
+					patch.addEvent(event);
+				}
+				if (patch.isReady() && patch.isInit())
+				{
+					optimizerOf(patch).optimize(patch);
+					updateNumOfEvents(patch);
+				}
+			}
+		}
+	}
+
+	// the same for a chunk of the stream, all patches in lock-step rounds (see the header comment)
+	void updatePatches(const std::vector<common::EventSample>& chunk)
+	{
+		const size_t n = chunk.size();
+		if (n == 0 || patches_.empty())
+		{
+			return;
+		}
+		const std::vector<ebo_event> ev = common::toEboEvents(chunk);
+		check(ebo_route_set_events(ctx_, ev.data(), n));
+		const size_t np = patches_.size();
+		std::vector<uint32_t> cursor(np, 0);
+		std::vector<int> live;  // patches still consuming the chunk
+		for (size_t i = 0; i < np; ++i)
+		{
+			Patch& p = patches_[i];
+			if (p.isLost())
+			{
+				continue;
+			}
+			if (!p.isInit())
+			{
+				// never optimised (:608): it only collects events; no rect change, no round needed
+				for (const auto& e : chunk)
+				{
+					if (p.isInPatch(e.value.point))
+					{
+						p.addEvent(e);
+					}
+				}
+				continue;
+			}
+			live.push_back(static_cast<int>(i));
+		}
+		rounds_ = 0;
+		std::vector<double> rects;
+		std::vector<uint32_t> start, take, index, count, next;
+		while (!live.empty())
+		{
+			++rounds_;
+			const int k = static_cast<int>(live.size());
+			rects.resize(4 * static_cast<size_t>(k));
+			start.resize(k);
+			take.resize(k);
+			count.assign(k, 0);
+			next.assign(k, 0);
+			uint32_t cap = 1;
+			for (int j = 0; j < k; ++j)
+			{
+				const Patch& p = patches_[live[j]];
+				const Rect2d& r = p.getPatch();
+				rects[4 * j + 0] = r.x;
+				rects[4 * j + 1] = r.y;
+				rects[4 * j + 2] = r.width;
+				rects[4 * j + 3] = r.height;
+				start[j] = cursor[live[j]];
+				// events still missing for isReady(): counter_ >= 30 && events_.size() >= numOfEvents_.
+				// Already ready (its state was changed from outside): the reference optimises it at the
+				// very next event of the stream, after adding that event if it is inside.
+				take[j] = static_cast<uint32_t>(p.eventsUntilReady());
+				cap = std::max(cap, take[j]);
+			}
+			index.assign(static_cast<size_t>(k) * cap, 0);
+			check(ebo_route_events(ctx_, k, rects.data(), start.data(), take.data(), cap, index.data(), count.data(),
+								   next.data()));
+			std::vector<int> still;
+			std::map<int64_t, std::vector<Patch*>> ready;
+			for (int j = 0; j < k; ++j)
+			{
+				const int i = live[j];
+				Patch& p = patches_[i];
+				if (take[j] == 0)
+				{
+					const common::EventSample& e = chunk[cursor[i]];
+					if (p.isInPatch(e.value.point))
+					{
+						p.addEvent(e);
+					}
+					cursor[i] += 1;
+					ready[p.getInitTime().count()].push_back(&p);
+					still.push_back(i);
+					continue;
+				}
+				for (uint32_t q = 0; q < count[j]; ++q)
+				{
+					p.addEvent(chunk[index[static_cast<size_t>(j) * cap + q]]);
+				}
+				cursor[i] = next[j];
+				if (count[j] == take[j])
+				{
+					ready[p.getInitTime().count()].push_back(&p);
+					still.push_back(i);
+				}
+				// else: the chunk ran out before the patch became ready
+			}
+			for (auto& group : ready)
+			{
+				auto it = optimizers_.find(group.first);
+				if (it == optimizers_.end() || !it->second)
+				{
+					throw std::runtime_error("tracker::TrackedPatches: no optimizer for a patch's init time");
+				}
+				it->second->optimize(group.second);
+				for (Patch* p : group.second)
+				{
+					updateNumOfEvents(*p);  // also after a patch was lost in optimize, as :613-614
+				}
+			}
+			live.clear();
+			for (int i : still)
+			{
+				if (!patches_[i].isLost() && cursor[i] < n)
+				{
+					live.push_back(i);
+				}
+			}
+		}
+	}
+
+	int lastRounds() const { return rounds_; }
+	ebo_ctx* handle() { return ctx_; }
+
+   private:
+	Optimizer& optimizerOf(const Patch& patch)
+	{
+		auto it = optimizers_.find(patch.getInitTime().count());
+		if (it == optimizers_.end() || !it->second)
+		{
+			throw std::runtime_error("tracker::TrackedPatches: no optimizer for a patch's init time");
+		}
+		return *it->second;
+	}
+	void check(int rc)
+	{
+		if (rc != EBO_OK)
+		{
+			throw std::runtime_error(std::string("tracker::TrackedPatches: ") + ebo_last_error(ctx_));
+		}
+	}
+
+	Size imageSize_;
+	int initNumEvents_;
+	ebo_ctx* ctx_ = nullptr;
+	Patches patches_;
+	std::map<int64_t, std::shared_ptr<Optimizer>> optimizers_;
+	std::function<size_t(const Patch&)> estimator_;
+	int rounds_ = 0;
+};
+
+}  // namespace tracker

@@ -4,14 +4,17 @@
 // CPU oracle.  Mirrors the style of the reference's own gtest files; gtest is not in
 // this image, so plain checks.  Run by tests/test_gpu_facade.py on the GPU box.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <memory>
 
 #include "../../event-based-odomety_amd/include/feature_tracker/contrast_functor.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/feature_detector.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/optimizer.h"
+#include "../../event-based-odomety_amd/include/feature_tracker/tracked_patches.h"
 #include "../../event-based-odomety_amd/include/feature_tracker/total_variance.h"
 #include "../../event-based-odomety_amd/include/tools/event_pump.h"
 #include "../../oracle/ebo_oracle.h"
@@ -487,6 +490,166 @@ int main()
 		}
 		optimizer.optimize(single);
 		EXPECT_TRUE(single.getFinalCosts().size() == 1 && single.getTrajectory().size() == 2);
+	}
+
+	// ---- FeatureDetector::updatePatches (feature_detector.cpp:585-619): the per-event call against
+	// the chunked one (device routing + lock-step rounds) on the same stream ----------------------
+	{
+		const int W = 240, H = 180;
+		tracker::Mat64 gx(H, W), gy(H, W);
+		for (int y = 0; y < H; ++y)
+		{
+			for (int x = 0; x < W; ++x)
+			{
+				double vx = 0, vy = 0;
+				for (int k = 0; k < 5; ++k)
+				{
+					const double cx = 40 + 38 * k, cy = 40 + 25 * k, sg = 6 + k;
+					const double e = std::exp(-((x - cx) * (x - cx) + (y - cy) * (y - cy)) / (2 * sg * sg));
+					vx += -(x - cx) / (sg * sg) * e;
+					vy += -(y - cy) / (sg * sg) * e;
+				}
+				gx.at<double>(y, x) = vx;
+				gy.at<double>(y, x) = vy;
+			}
+		}
+		tracker::OptimizerParams op;
+		auto build = [&](tracker::TrackedPatches& tp) {
+			auto opt = std::make_shared<tracker::Optimizer>(op, tracker::Size(W, H));
+			opt->setGrad(gx, gy);
+			tp.setOptimizer(common::timestamp_t(1000), opt);
+			for (int k = 0; k < 4; ++k)
+			{
+				tracker::Patch p(tracker::Corner(42.0 + 38 * k, 38.0 + 25 * k), 12, common::timestamp_t(1000));
+				p.setTrackId(k);
+				p.setFlowDir(0.4 + 0.3 * k);
+				tp.addPatch(p);
+			}
+			// a patch nobody initialised (collects events, is never optimised) and one that starts
+			// next to the border (lost by updateNumOfEvents after its first optimisation)
+			tracker::Patch cold(tracker::Corner(120.0, 90.0), 12, common::timestamp_t(1000));
+			tp.addPatch(cold);
+			tracker::Patch edge(tracker::Corner(4.0, 100.0), 12, common::timestamp_t(1000));
+			edge.setFlowDir(0.2);
+			tp.addPatch(edge);
+			return opt;
+		};
+		// a stream: events drifting over the blobs (plus noise), 6000 of them
+		std::vector<common::EventSample> stream;
+		uint64_t st = 12345;
+		auto rnd = [&]() {
+			st = st * 6364136223846793005ull + 1442695040888963407ull;
+			return static_cast<uint32_t>(st >> 33);
+		};
+		for (int i = 0; i < 6000; ++i)
+		{
+			common::EventSample e;
+			const int k = static_cast<int>(rnd() % 6);
+			const double drift = 1e-3 * i;
+			int x, y;
+			if (k < 4)
+			{
+				x = static_cast<int>(42.0 + 38 * k + drift + static_cast<int>(rnd() % 21) - 10);
+				y = static_cast<int>(38.0 + 25 * k + static_cast<int>(rnd() % 21) - 10);
+			}
+			else if (k == 4)
+			{
+				x = static_cast<int>(rnd() % W);
+				y = static_cast<int>(rnd() % H);
+			}
+			else
+			{
+				x = static_cast<int>(4 + rnd() % 22);
+				y = static_cast<int>(90 + rnd() % 22);
+			}
+			e.value.point = {x, y};
+			e.value.sign = (rnd() & 1) ? common::POSITIVE : common::NEGATIVE;
+			e.timestamp = common::timestamp_t(2000 + 37 * i);
+			stream.push_back(e);
+		}
+		tracker::TrackedPatches seq(tracker::Size(W, H)), bat(tracker::Size(W, H));
+		auto optSeq = build(seq);
+		auto optBat = build(bat);
+		for (const auto& e : stream)
+		{
+			seq.updatePatches(e);
+		}
+		// two chunks, so that state carries over a chunk border
+		std::vector<common::EventSample> a(stream.begin(), stream.begin() + 2500), b(stream.begin() + 2500, stream.end());
+		bat.updatePatches(a);
+		const int roundsA = bat.lastRounds();
+		bat.updatePatches(b);
+		std::printf("updatePatches: %zu optimisations per-event, %zu chunked, rounds %d + %d\n",
+					optSeq->getFinalCosts().size(), optBat->getFinalCosts().size(), roundsA, bat.lastRounds());
+		EXPECT_TRUE(optSeq->getFinalCosts().size() == optBat->getFinalCosts().size());
+		EXPECT_TRUE(optSeq->getFinalCosts().size() >= 8);
+		for (size_t i = 0; i < seq.getPatches().size(); ++i)
+		{
+			const tracker::Patch& p = seq.getPatches()[i];
+			const tracker::Patch& q = bat.getPatches()[i];
+			EXPECT_TRUE(p.isLost() == q.isLost() && p.isInit() == q.isInit());
+			EXPECT_TRUE(p.getFinalCosts().size() == q.getFinalCosts().size());
+			EXPECT_TRUE(p.getTrajectory().size() == q.getTrajectory().size());
+			EXPECT_TRUE(p.getEvents().size() == q.getEvents().size());
+			EXPECT_TRUE(p.eventsUntilReady() == q.eventsUntilReady());
+			bool sameEvents = p.getEvents().size() == q.getEvents().size();
+			for (size_t k = 0; sameEvents && k < p.getEvents().size(); ++k)
+			{
+				sameEvents = p.getEvents()[k].timestamp == q.getEvents()[k].timestamp &&
+							 p.getEvents()[k].value.point.x == q.getEvents()[k].value.point.x;
+			}
+			EXPECT_TRUE(sameEvents);
+			// the same calls in the same order on the same device code: identical, not just close
+			EXPECT_TRUE(p.getPatch().x == q.getPatch().x && p.getPatch().y == q.getPatch().y);
+			for (int k = 0; k < 4; ++k)
+			{
+				EXPECT_TRUE(p.getWarp().data()[k] == q.getWarp().data()[k]);
+			}
+			for (size_t k = 0; k < p.getFinalCosts().size() && k < q.getFinalCosts().size(); ++k)
+			{
+				EXPECT_TRUE(p.getFinalCosts()[k] == q.getFinalCosts()[k]);
+			}
+			std::printf("  patch %zu: %zu optimisations, lost %d, centre (%.4f, %.4f)\n", i, p.getFinalCosts().size(),
+						int(p.isLost()), p.toCorner().x, p.toCorner().y);
+		}
+		// timing, 100 tracked patches (25 copies of the four) over the same 6000-event stream
+		{
+			auto many = [&](tracker::TrackedPatches& tp) {
+				auto opt = std::make_shared<tracker::Optimizer>(op, tracker::Size(W, H));
+				opt->setGrad(gx, gy);
+				tp.setOptimizer(common::timestamp_t(1000), opt);
+				for (int c = 0; c < 25; ++c)
+				{
+					for (int k = 0; k < 4; ++k)
+					{
+						tracker::Patch p(tracker::Corner(42.0 + 38 * k, 38.0 + 25 * k), 12, common::timestamp_t(1000));
+						p.setFlowDir(0.4 + 0.3 * k);
+						tp.addPatch(p);
+					}
+				}
+				return opt;
+			};
+			tracker::TrackedPatches s100(tracker::Size(W, H)), b100(tracker::Size(W, H));
+			auto o1 = many(s100);
+			auto o2 = many(b100);
+			const auto t0 = std::chrono::steady_clock::now();
+			for (const auto& e : stream)
+			{
+				s100.updatePatches(e);
+			}
+			const auto t1 = std::chrono::steady_clock::now();
+			b100.updatePatches(stream);
+			const auto t2 = std::chrono::steady_clock::now();
+			std::printf("updatePatches, 100 patches x 6000 events: per-event %.1f ms (%zu optimisations), chunked %.1f ms "
+						"(%zu optimisations in %d rounds)\n",
+						std::chrono::duration<double, std::milli>(t1 - t0).count(), o1->getFinalCosts().size(),
+						std::chrono::duration<double, std::milli>(t2 - t1).count(), o2->getFinalCosts().size(),
+						b100.lastRounds());
+			EXPECT_TRUE(o1->getFinalCosts().size() == o2->getFinalCosts().size());
+			EXPECT_TRUE(s100.getPatches()[57].getPatch().x == b100.getPatches()[57].getPatch().x);
+		}
+		EXPECT_TRUE(seq.getPatches()[4].getFinalCosts().empty());   // never initialised
+		EXPECT_TRUE(seq.getPatches()[5].isLost() && seq.getPatches()[5].getFinalCosts().size() == 1);  // centre within 5 px of the border
 	}
 
 	std::printf(g_fail ? "facade_test: %d FAILED\n" : "facade_test: all passed\n", g_fail);
