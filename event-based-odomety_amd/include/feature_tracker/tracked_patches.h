@@ -63,6 +63,7 @@ class TrackedPatches
 
 	Patches& getPatches() { return patches_; }
 	Patches const& getPatches() const { return patches_; }
+	void setPatches(const Patches& patches) { patches_ = patches; }  // feature_detector.h:72
 	void addPatch(const Patch& patch) { patches_.push_back(patch); }
 
 	// optimizers_[image.timestamp.count()] of the reference (:560-563): the optimizer holding the

@@ -492,6 +492,51 @@ int main()
 		EXPECT_TRUE(single.getFinalCosts().size() == 1 && single.getTrajectory().size() == 2);
 	}
 
+	// ---- the reference's own updatePatchTest (feature_detector_test.cpp:43-97): three patches of
+	// extent 11 at (0,0), (5,5), (20,20), events in [0,30)^2; the detector's patches hold the events
+	// a manual isInPatch/addEvent loop gives them -- per event and as one chunk ---------------------
+	{
+		const common::timestamp_t timestamp(0);
+		tracker::Patches patches = {tracker::Patch({0, 0}, 11, timestamp), tracker::Patch({5, 5}, 11, timestamp),
+									tracker::Patch({20, 20}, 11, timestamp)};
+		tracker::TrackedPatches detector(tracker::Size(240, 180)), chunked(tracker::Size(240, 180));
+		detector.setPatches(patches);
+		chunked.setPatches(patches);
+		std::vector<common::EventSample> all;
+		std::srand(7);
+		for (size_t i = 0; i < 200; ++i)
+		{
+			common::EventSample event;
+			event.timestamp = common::timestamp_t(i);
+			event.value.point = {std::rand() % 30, std::rand() % 30};
+			event.value.sign = std::rand() % 2 == 1 ? common::POSITIVE : common::NEGATIVE;
+			detector.updatePatches(event);
+			all.push_back(event);
+			for (auto& patch : patches)
+			{
+				if (patch.isInPatch(event.value.point))
+				{
+					patch.addEvent(event);
+				}
+			}
+		}
+		chunked.updatePatches(all);
+		for (const tracker::TrackedPatches* d : {&detector, &chunked})
+		{
+			EXPECT_TRUE(d->getPatches().size() == patches.size());
+			for (size_t i = 0; i < patches.size(); ++i)
+			{
+				const auto& got = d->getPatches()[i].getEvents();
+				const auto& want = patches[i].getEvents();
+				EXPECT_TRUE(got.size() == want.size() && !want.empty());
+				for (size_t k = 0; k < got.size() && k < want.size(); ++k)
+				{
+					EXPECT_TRUE(got[k].timestamp == want[k].timestamp);
+				}
+			}
+		}
+	}
+
 	// ---- FeatureDetector::updatePatches (feature_detector.cpp:585-619): the per-event call against
 	// the chunked one (device routing + lock-step rounds) on the same stream ----------------------
 	{

@@ -141,6 +141,29 @@ def test_patch_rect2d_membership_half_open(orc):
     assert nabla.sum() == 2.0
 
 
+def test_update_patches_routing_reference_scenario(orc):
+    """feature_detector_test.cpp:43-97 (updatePatchTest): patches of extent 11 at (0,0), (5,5),
+    (20,20), events in [0,30)^2; a patch's events are those a plain isInPatch test selects, in
+    stream order.  Also the quota / start / next bookkeeping the batched caller relies on."""
+    rng = np.random.RandomState(3)
+    n = 400
+    x, y = rng.randint(0, 30, n), rng.randint(0, 30, n)
+    ev = orc.make_events(x, y, np.arange(n), np.where(rng.rand(n) < 0.5, 1, -1))
+    rects = np.array([[c - 11.0, c - 11.0, 23.0, 23.0] for c in (0.0, 5.0, 20.0)])
+    inside = [np.flatnonzero((rects[p, 0] <= x) & (x < rects[p, 0] + 23) & (rects[p, 1] <= y) & (y < rects[p, 1] + 23))
+              for p in range(3)]
+    got, nxt = orc.route_events(ev, rects, [0, 0, 0], [10**6] * 3, n)
+    for p in range(3):
+        assert np.array_equal(got[p], inside[p])
+    assert list(nxt) == [n, n, n]
+    # quota 30 from a late start: the 30 first members at or after `start`, next = after the 30th
+    got, nxt = orc.route_events(ev, rects, [50, 0, 399], [30, 0, 5], 64)
+    late = inside[0][inside[0] >= 50]
+    assert np.array_equal(got[0], late[:30]) and nxt[0] == late[29] + 1
+    assert len(got[1]) == 0 and nxt[1] == 0          # quota 0: nothing taken, nothing skipped
+    assert nxt[2] == n                                # chunk exhausted before the quota
+
+
 def test_patch_integrate_mc_round_half_even(orc):
     # patch.cpp:118-119 Point2d -> Point2i is cvRound (half to even), SURVEY F7.
     # one event at x=10, flow so that compensated x = 10.5 and 11.5
