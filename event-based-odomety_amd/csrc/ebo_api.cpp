@@ -551,6 +551,7 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 	int rc = EBO_OK;
 	if (nf > c->pin_cap)
 	{
+		(void)hipSetDevice(c->prm.device);  // the staging is mapped for the context's device
 		if (c->pin_flows)
 		{
 			(void)hipHostFree(c->pin_flows);
