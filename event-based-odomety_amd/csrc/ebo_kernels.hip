@@ -1205,7 +1205,7 @@ __device__ __forceinline__ void stray_flow(uint64_t rec, const double* __restric
 // those that land in its band with ds_add_u32, and writes the finished f64 rows
 // with plain coalesced stores.  HBM traffic = events once + image once: no global
 // atomics, no int32 intermediate image.  Bit-exact (integer adds commute).
-template <bool U16, int MODE>
+template <bool U16, int MODE, bool MULTI>
 __global__ void __launch_bounds__(1024) k_count_window_lds(
 	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
 	const void* __restrict__ aux, int rowsPerBand, int nWindows, double* __restrict__ image,
@@ -1279,8 +1279,28 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 			for (int k = 0; k < kInFlight; ++k)
 			{
 				const bool live = eb + k * blockDim.x < evEnd;
-				int nx, ny;
-				const bool hit = count_target<MODE>(recs[k], live, dtWin[k], m0[k], m1[k], windowField, c, nx, ny);
+				int nx = 0, ny = -1;
+				bool hit = false;
+				bool maybe = true;
+				if (MODE == 1 && MULTI)
+				{
+					// Several bands (MULTI): every band workgroup sees every event of the window, but only the
+					// events that land in its rows need the exact (f64, reference-order) warp.  A float
+					// estimate of the destination row decides: its error is below 2e-7 of the
+					// displacement plus 6e-8 of the row, so an estimate more than a row outside the band
+					// cannot round into it (a displacement large enough to break that bound leaves the
+					// image anyway); NaN compares false and takes the exact path.  Events of a wave
+					// belong to one or two patches, so whole waves skip.
+					int x, y, pos, dt;
+					unpack(recs[k], x, y, pos, dt);
+					const float fy = static_cast<float>(y) + static_cast<float>(dt + dtWin[k]) * static_cast<float>(c.scale) *
+															   static_cast<float>(m1[k]);
+					maybe = !(fy < static_cast<float>(row0) - 1.5f || fy > static_cast<float>(row0 + rows) + 0.5f);
+				}
+				if (maybe)
+				{
+					hit = count_target<MODE>(recs[k], live, dtWin[k], m0[k], m1[k], windowField, c, nx, ny);
+				}
 				const int ry = ny - row0;
 				if (hit && ry >= 0 && ry < rows)
 				{
@@ -2485,12 +2505,13 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		const bool want = L.impl == 1 || (L.impl < 0 && L.mode != 0 && bands <= 4 && L.n_windows * bands >= 64);
 		if (want && rowsPerBand > 0 && L.n_units_total > 0)
 		{
-			auto kern = u16 ? (L.mode == 0	 ? k_count_window_lds<true, 0>
-							   : L.mode == 1 ? k_count_window_lds<true, 1>
-											 : k_count_window_lds<true, 2>)
-							: (L.mode == 0	 ? k_count_window_lds<false, 0>
-							   : L.mode == 1 ? k_count_window_lds<false, 1>
-											 : k_count_window_lds<false, 2>);
+			const bool multi = bands > 1 && L.mode == 1;  // float pre-test of the destination row
+			auto kern = u16 ? (L.mode == 0	 ? k_count_window_lds<true, 0, false>
+							   : L.mode == 1 ? (multi ? k_count_window_lds<true, 1, true> : k_count_window_lds<true, 1, false>)
+											 : k_count_window_lds<true, 2, false>)
+							: (L.mode == 0	 ? k_count_window_lds<false, 0, false>
+							   : L.mode == 1 ? (multi ? k_count_window_lds<false, 1, true> : k_count_window_lds<false, 1, false>)
+											 : k_count_window_lds<false, 2, false>);
 			const size_t lds = (static_cast<size_t>(rowsPerBand) * L.c.image_w * (u16 ? 2 : 4) + 3) & ~size_t(3);
 			if (allow_big_lds(kern, lds))
 			{
