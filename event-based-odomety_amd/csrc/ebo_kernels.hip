@@ -1158,12 +1158,33 @@ __device__ __forceinline__ bool count_target(uint64_t rec, bool live, int dtWin,
 			m0 = static_cast<double>(f.x);
 			m1 = static_cast<double>(f.y);
 		}
-		const double dtw = static_cast<double>(dt + dtWin);
-		const double fx = static_cast<double>(x) + dtw * c.scale * m0;
-		const double fy = static_cast<double>(y) + dtw * c.scale * m1;
-		live = live && convertible(fx) && convertible(fy);
-		nx = static_cast<int>(round(live ? fx : 0.0));
-		ny = static_cast<int>(round(live ? fy : 0.0));
+		// Float first.  The reference's position is fl64(x + fl64(fl64(dtw * scale) * m)); the same
+		// expression in float differs from it by at most 4e-7 |displacement| + 6e-8 |x| (five
+		// roundings of 2^-24 on the product, one on the sum, inputs rounded to float), and
+		// |x| < 2^15.  If the float value is farther than that from every half-integer, both round
+		// to the same pixel, and the double arithmetic (quarter-rate conversions, truncations and
+		// compares: the warped count kernels are instruction-bound on it) is not needed.  Anything
+		// else -- a value near a rounding boundary (0.4 % of the events), huge, infinite or NaN
+		// (comparisons false) -- takes the exact path below.
+		const float prod = static_cast<float>(dt + dtWin) * static_cast<float>(c.scale);
+		const float px = prod * static_cast<float>(m0), py = prod * static_cast<float>(m1);
+		const float vx = static_cast<float>(x) + px, vy = static_cast<float>(y) + py;
+		const float rx = rintf(vx), ry = rintf(vy);
+		const bool sure = fabsf(vx - rx) < 0.498f - 4e-7f * fabsf(px) && fabsf(vy - ry) < 0.498f - 4e-7f * fabsf(py);
+		if (sure)
+		{
+			nx = static_cast<int>(rx);
+			ny = static_cast<int>(ry);
+		}
+		else
+		{
+			const double dtw = static_cast<double>(dt + dtWin);
+			const double fx = static_cast<double>(x) + dtw * c.scale * m0;
+			const double fy = static_cast<double>(y) + dtw * c.scale * m1;
+			live = live && convertible(fx) && convertible(fy);
+			nx = static_cast<int>(round(live ? fx : 0.0));
+			ny = static_cast<int>(round(live ? fy : 0.0));
+		}
 	}
 	return live && nx >= 0 && nx < c.image_w && ny >= 0 && ny < c.image_h;
 }
@@ -1230,12 +1251,33 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 	{
 		cnt[i] = 0u;
 	}
-	__syncthreads();
 	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
 	const int P = c.npx * c.npy;
 	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
 	const double* windowFlows = static_cast<const double*>(aux) + (MODE == 1 ? 2 * static_cast<size_t>(w) * P : 0);
 	const float* windowField = static_cast<const float*>(aux) + (MODE == 2 ? 2 * static_cast<size_t>(w) * imgSize : 0);
+	// The window's unit table -- reference-time offset per unit, flow per patch -- behind the
+	// counters in LDS: every event looks its unit up (event_unit), and three gathers per event
+	// through the vector memory path cost more than the warp arithmetic (an LDS read of an
+	// address shared by most of a wave is a broadcast).
+	const int tblBase = (rowsPerBand * W * (U16 ? 2 : 4) + 15) & ~15;  // bytes; the band size of the launch
+	double* tblFlow = reinterpret_cast<double*>(reinterpret_cast<char*>(cnt) + tblBase);
+	int* tblDt = reinterpret_cast<int*>(tblFlow + (MODE == 1 ? 2 * P : 0));
+	if (MODE != 0)
+	{
+		for (int i = threadIdx.x; i <= P; i += blockDim.x)
+		{
+			tblDt[i] = wu[i].dt_win;
+		}
+		if (MODE == 1)
+		{
+			for (int i = threadIdx.x; i < 2 * P; i += blockDim.x)
+			{
+				tblFlow[i] = windowFlows[i];
+			}
+		}
+	}
+	__syncthreads();
 	// kInFlight independent 8-byte loads per lane are issued before the first is
 	// consumed: ~64 KiB in flight per CU, enough to cover HBM latency (Little's law).
 	constexpr int kInFlight = 8;
@@ -1267,11 +1309,11 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 				{
 					int patch, unit;
 					event_unit(recs[k], c, patch, unit);
-					dtWin[k] = wu[unit].dt_win;
+					dtWin[k] = tblDt[unit];
 					if (MODE == 1)
 					{
-						m0[k] = windowFlows[2 * patch];
-						m1[k] = windowFlows[2 * patch + 1];
+						m0[k] = tblFlow[2 * patch];
+						m1[k] = tblFlow[2 * patch + 1];
 					}
 				}
 			}
@@ -2498,11 +2540,16 @@ int launch_count_image(const CountLaunch& L, void* stream)
 	// enough (band, window) workgroups to occupy the chip; else global int atomics.
 	{
 		const bool u16 = L.max_window_events < 65536;
-		const size_t ldsBytes = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 128) * 1024;
+		const int Pn = L.c.npx * L.c.npy;
+		// unit table behind the counters: flows [P][2] f64 (mode 1) + dt_win [P + 1] i32
+		const size_t tblBytes = L.mode == 0 ? 0 : (L.mode == 1 ? static_cast<size_t>(Pn) * 16 : 0) + static_cast<size_t>(Pn + 1) * 4 + 16;
+		const size_t ldsWant = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 128) * 1024;
+		const size_t ldsBytes = std::min(ldsWant, static_cast<size_t>(160 * 1024 - 1024) - std::min(tblBytes, static_cast<size_t>(96 * 1024)));
 		const size_t pxPerBand = u16 ? ldsBytes / 2 : ldsBytes / 4;
 		const int rowsPerBand = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
 		const int bands = rowsPerBand > 0 ? (L.c.image_h + rowsPerBand - 1) / rowsPerBand : 1 << 30;
-		const bool want = L.impl == 1 || (L.impl < 0 && L.mode != 0 && bands <= 4 && L.n_windows * bands >= 64);
+		const bool tableFits = tblBytes <= 64 * 1024;  // finer grids: the other implementations
+		const bool want = tableFits && (L.impl == 1 || (L.impl < 0 && L.mode != 0 && bands <= 4 && L.n_windows * bands >= 64));
 		if (want && rowsPerBand > 0 && L.n_units_total > 0)
 		{
 			const bool multi = bands > 1 && L.mode == 1;  // float pre-test of the destination row
@@ -2512,7 +2559,11 @@ int launch_count_image(const CountLaunch& L, void* stream)
 							: (L.mode == 0	 ? k_count_window_lds<false, 0, false>
 							   : L.mode == 1 ? (multi ? k_count_window_lds<false, 1, true> : k_count_window_lds<false, 1, false>)
 											 : k_count_window_lds<false, 2, false>);
-			const size_t lds = (static_cast<size_t>(rowsPerBand) * L.c.image_w * (u16 ? 2 : 4) + 3) & ~size_t(3);
+			const size_t lds = ((static_cast<size_t>(rowsPerBand) * L.c.image_w * (u16 ? 2 : 4) + 15) & ~size_t(15)) + tblBytes;
+			if (lds > 160 * 1024)
+			{
+				return -2;
+			}
 			if (allow_big_lds(kern, lds))
 			{
 				return -2;
