@@ -63,6 +63,24 @@ def test_edge_eval_value_and_jacobian(ebo, orc, synth, config, n_events):
             assert np.all(r[0][active == 0] == 0.0)
 
 
+@pytest.mark.parametrize("forms,layout", [("0", "0"), ("0", "1"), ("1", "0"), ("7", "0"), ("7", "1")])
+def test_edge_tensor_filter_forms_and_layouts(ebo, orc, synth, monkeypatch, forms, layout):
+    """Every selectable form of the structure-tensor filter (direct 49-tap, band buffers, register
+    runs) on both LDS layouts gives the oracle's value and Jacobian (random flows: no exact ties)."""
+    monkeypatch.setenv("EBO_EDGE_SEPARABLE", forms)
+    monkeypatch.setenv("EBO_EDGE_LAYOUT", layout)
+    ev, gt = synth.make_window(0, n_events=15000)
+    with ctx_for(ebo, synth, 0) as c:
+        c.set_window(ev)
+        prm = oparams(orc, c.params)
+        flows = np.random.RandomState(11).uniform(-0.8, 0.8, (c.P, 2))
+        r, J = c.eval(flows)
+        ro, Jo, _, _ = orc.window_eval(ev, prm, flows)
+        check_rj(r[0], J[0], ro, Jo)
+        r1, _ = c.eval(flows, want_jac=False)
+        np.testing.assert_allclose(r1[0], ro, rtol=1e-9)
+
+
 def test_edge_penalty_branch_and_sparse_images(ebo, orc, synth):
     """mean(image) <= 1e-4 => 1e3 (1 + |m|^2) (contrast_functor.h:159-165): huge flows, and
     flows that leave only a handful of events inside the window."""
