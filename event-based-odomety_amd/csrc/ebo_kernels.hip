@@ -1397,12 +1397,24 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 template <bool U16, int MODE>
 __global__ void __launch_bounds__(512) k_count_bands(
 	const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
-	const void* __restrict__ aux, int patchRowsPerBand, int nRegular, double* __restrict__ image,
+	const void* __restrict__ aux, int patchRowsPerBand, int nRegular, int colTiles, double* __restrict__ image,
 	unsigned long long* __restrict__ ovf /* [0] = count, then entries */, EvalConsts c)
 {
 	extern __shared__ unsigned int cnt[];
 	const int w = blockIdx.y;
-	const int band = blockIdx.x;
+	// colTiles > 1 (large sensors, one patch row per band): the band is cut into column tiles of
+	// whole patches -- the units of a tile are still one contiguous event range -- so that the
+	// counters of a workgroup stay small enough for several workgroups per CU
+	const int band = blockIdx.x / colTiles;
+	const int tile = blockIdx.x - band * colTiles;
+	const int unitsPerTile = (c.npx + colTiles - 1) / colTiles;
+	const int uLo = min(tile * unitsPerTile, c.npx), uHi = min(uLo + unitsPerTile, c.npx);
+	const int x0 = uLo * c.patch_w;
+	const int x1 = (uHi == c.npx) ? c.image_w : uHi * c.patch_w;
+	if (uLo >= uHi)
+	{
+		return;
+	}
 	// bands 0..nRegular-1: patchRowsPerBand whole patch rows each, over patch rows [0, npy-1);
 	// then the last patch row (which absorbs the remainder of the image height and can be
 	// almost twice as tall) in sub-bands of at most patchRowsPerBand * patch_h rows.
@@ -1429,7 +1441,8 @@ __global__ void __launch_bounds__(512) k_count_bands(
 	const int regionRow1 = (pr1 == c.npy) ? c.image_h : pr1 * c.patch_h;
 	const int rows = row1 - row0;
 	const int W = c.image_w;
-	const int npx = rows * W;
+	const int tw = x1 - x0;  // == W without column tiles
+	const int npx = rows * tw;
 	const int nWords = U16 ? (npx + 1) >> 1 : npx;
 	for (int i = threadIdx.x; i < nWords; i += blockDim.x)
 	{
@@ -1442,11 +1455,11 @@ __global__ void __launch_bounds__(512) k_count_bands(
 	const double* windowFlows = static_cast<const double*>(aux) + (MODE == 1 ? 2 * static_cast<size_t>(w) * P : 0);
 	const float* windowField = static_cast<const float*>(aux) + (MODE == 2 ? 2 * static_cast<size_t>(w) * imgSize : 0);
 	constexpr int kInFlight = 8;
-	// pass 0: the band's own patch units; pass 1 (band 0 only): the stray unit
-	for (int pass = 0; pass < (band == 0 ? 2 : 1); ++pass)
+	// pass 0: the band's own patch units; pass 1 (band 0, tile 0 only): the stray unit
+	for (int pass = 0; pass < ((band == 0 && tile == 0) ? 2 : 1); ++pass)
 	{
-		int ui = pass == 0 ? pr0 * c.npx : P;
-		const int uLast = pass == 0 ? pr1 * c.npx - 1 : P;
+		int ui = pass == 0 ? pr0 * c.npx + uLo : P;
+		const int uLast = pass == 0 ? (pr1 - 1) * c.npx + uHi - 1 : P;
 		const uint32_t evBegin = wu[ui].ev_off;
 		const uint32_t evEnd = wu[uLast].ev_off + wu[uLast].n_ev;
 		uint32_t uEnd = wu[ui].ev_off + wu[ui].n_ev;
@@ -1495,10 +1508,10 @@ __global__ void __launch_bounds__(512) k_count_bands(
 				int nx, ny;
 				const bool live = count_target<MODE>(recs[k], inRange, dtWin, m0, m1, windowField, c, nx, ny);
 				const int ry = ny - row0;
-				const bool inBand = live && ry >= 0 && ry < rows;
+				const bool inBand = live && ry >= 0 && ry < rows && nx >= x0 && nx < x1;
 				if (inBand)
 				{
-					const int p = ry * W + nx;
+					const int p = ry * tw + (nx - x0);
 					if (U16)
 					{
 						atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
@@ -1511,7 +1524,7 @@ __global__ void __launch_bounds__(512) k_count_bands(
 				// (a stray event is streamed by this workgroup only; an own event that lands in
 				// another sub-band of the same patch row is counted there)
 				const bool spill = MODE != 0 && live && !inBand &&
-								   (stray || (reportsOutside && (ny < regionRow0 || ny >= regionRow1)));
+								   (stray || (reportsOutside && (ny < regionRow0 || ny >= regionRow1 || nx < x0 || nx >= x1)));
 				const unsigned long long spillMask = __ballot(spill);
 				if (spillMask != 0ull)
 				{
@@ -1540,7 +1553,17 @@ __global__ void __launch_bounds__(512) k_count_bands(
 	}
 	__syncthreads();
 	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W;
-	if (U16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+	if (tw != W)
+	{
+		// column tile: row segments of tw pixels
+		for (int p = threadIdx.x; p < npx; p += blockDim.x)
+		{
+			const int r = p / tw, lx = p - r * tw;
+			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
+			out[static_cast<size_t>(r) * W + x0 + lx] = static_cast<double>(v);
+		}
+	}
+	else if (U16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
 	{
 		const int pairs = npx >> 1;
 		double2* out2 = reinterpret_cast<double2*>(out);
@@ -2628,7 +2651,30 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		const size_t rowBytes = static_cast<size_t>(L.c.image_w) * (u16 ? 2 : 4);
 		const int prb = std::max(1, static_cast<int>(ldsBytes / rowBytes) / L.c.patch_h);
 		const int bandRows = prb * L.c.patch_h;
-		const size_t lds = (static_cast<size_t>(bandRows) * rowBytes + 3) & ~size_t(3);
+		// One patch row already above the target (large sensors; C4: 22 rows x 1280 x 4 B = 112 KB,
+		// one workgroup per CU): cut it into column tiles of whole patches.  Un-warped image only --
+		// with warping more events would leave a tile than a band.
+		int colTiles = 1;
+		size_t tileRowBytes = rowBytes;
+		if (L.mode == 0 && static_cast<size_t>(L.c.patch_h) * rowBytes > ldsBytes && L.c.npx > 1)
+		{
+			const size_t pxBytes = u16 ? 2 : 4;
+			const int unitsPerTile = std::max<int>(1, static_cast<int>(ldsBytes / (static_cast<size_t>(bandRows) * pxBytes)) / L.c.patch_w);
+			colTiles = (L.c.npx + unitsPerTile - 1) / unitsPerTile;
+			const int perTile = (L.c.npx + colTiles - 1) / colTiles;  // as the kernel divides them
+			const int lastLo = std::min((colTiles - 1) * perTile, L.c.npx - 1);
+			const int widest = std::max(perTile * L.c.patch_w, L.c.image_w - lastLo * L.c.patch_w);
+			tileRowBytes = static_cast<size_t>(widest) * pxBytes;
+		}
+		if (const char* v = std::getenv("EBO_COUNT_COLTILES"))  // A/B: 1 = off
+		{
+			if (std::atoi(v) == 1)
+			{
+				colTiles = 1;
+				tileRowBytes = rowBytes;
+			}
+		}
+		const size_t lds = (static_cast<size_t>(bandRows) * tileRowBytes + 3) & ~size_t(3);
 		auto kern = u16 ? (L.mode == 0	 ? k_count_bands<true, 0>
 						   : L.mode == 1 ? k_count_bands<true, 1>
 										 : k_count_bands<true, 2>)
@@ -2644,8 +2690,8 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			{
 				return -2;
 			}
-			hipLaunchKernelGGL(kern, dim3(nRegular + nSub, L.n_windows), dim3(512), lds, s, L.d_events, L.d_units,
-							   L.units_per_window, L.d_aux, prb, nRegular, L.d_image, L.d_overflow, L.c);
+			hipLaunchKernelGGL(kern, dim3((nRegular + nSub) * colTiles, L.n_windows), dim3(512), lds, s, L.d_events,
+							   L.d_units, L.units_per_window, L.d_aux, prb, nRegular, colTiles, L.d_image, L.d_overflow, L.c);
 			if (L.mode != 0)
 			{
 				hipLaunchKernelGGL(k_count_overflow, dim3(512), dim3(256), 0, s, L.d_overflow, L.d_image);
