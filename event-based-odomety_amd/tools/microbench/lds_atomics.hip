@@ -12,7 +12,9 @@ constexpr int ITERS = 2048;
 constexpr int LDS_ELEMS = 4096;  // 32 KB of 8-byte slots
 
 // pattern 0: lane-linear (conflict free), 1: pseudo-random per lane, 2: all lanes one address,
-// 3: 8 lanes share an address (8-way same-address), 4: stride 2 slots
+// 3: 8 lanes share an address (8-way same-address), 4: stride 2 slots,
+// 5: groups of 7 consecutive lanes on 7 consecutive slots from a random base per group (the
+//    'seven lanes per event' layout), 6: a random base per lane plus a common tap offset (today's)
 template <typename T, int PATTERN>
 __global__ void k_atomic(T* out, int iters)
 {
@@ -29,13 +31,56 @@ __global__ void k_atomic(T* out, int iters)
 		else if (PATTERN == 1) { rnd = rnd * 1664525u + 1013904223u; a = (rnd >> 10) & (LDS_ELEMS - 1); }
 		else if (PATTERN == 2) a = (it * 7) & (LDS_ELEMS - 1);
 		else if (PATTERN == 3) a = ((idx >> 3) + it * 8) & (LDS_ELEMS - 1);
-		else a = (idx * 2 + it * 128) & (LDS_ELEMS - 1);
+		else if (PATTERN == 4) a = (idx * 2 + it * 128) & (LDS_ELEMS - 1);
+		else if (PATTERN == 5)
+		{
+			// per step a fresh base per 7-lane group (hash of group id and step), lane adds its column
+			const unsigned g = (threadIdx.x & 63) / 7 + (threadIdx.x >> 6) * 9;
+			unsigned h = (g * 2654435761u) ^ ((it / 7) * 40503u + blockIdx.x * 97u);
+			h = h * 1664525u + 1013904223u;
+			a = ((h >> 10) + (threadIdx.x & 63) % 7 + (it % 7) * 41) & (LDS_ELEMS - 1);
+		}
+		else
+		{
+			if (it % 49 == 0) { rnd = rnd * 1664525u + 1013904223u; }
+			a = ((rnd >> 10) + (it % 7) + ((it / 7) % 7) * 41) & (LDS_ELEMS - 1);
+		}
 		atomicAdd(&lds[a], v);
 	}
 	__syncthreads();
 	T s = T(0);
 	for (int i = threadIdx.x; i < LDS_ELEMS; i += blockDim.x) s += lds[i];
 	if (s == T(12345)) out[blockIdx.x] = s;
+}
+
+// plain 8-byte LDS reads with the same address patterns (the gather pass)
+template <int PATTERN>
+__global__ void k_read(double* out, int iters)
+{
+	__shared__ double lds[LDS_ELEMS];
+	for (int i = threadIdx.x; i < LDS_ELEMS; i += blockDim.x) lds[i] = double(i);
+	__syncthreads();
+	unsigned rnd = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+	double acc = 0.0;
+	for (int it = 0; it < iters; ++it)
+	{
+		unsigned a;
+		if (PATTERN == 0) a = (threadIdx.x + it * 64) & (LDS_ELEMS - 1);
+		else if (PATTERN == 5)
+		{
+			const unsigned g = (threadIdx.x & 63) / 7 + (threadIdx.x >> 6) * 9;
+			unsigned h = (g * 2654435761u) ^ ((it / 7) * 40503u + blockIdx.x * 97u);
+			h = h * 1664525u + 1013904223u;
+			a = ((h >> 10) + (threadIdx.x & 63) % 7 + (it % 7) * 41) & (LDS_ELEMS - 1);
+		}
+		else
+		{
+			if (it % 49 == 0) { rnd = rnd * 1664525u + 1013904223u; }
+			a = ((rnd >> 10) + (it % 7) + ((it / 7) % 7) * 41) & (LDS_ELEMS - 1);
+		}
+		acc += lds[a];
+	}
+	if (acc == -1.0) out[blockIdx.x] = acc;  // never true (all values >= 0): keeps the loads alive
 }
 
 // non-atomic read-modify-write through LDS for comparison (races ignored: timing only)
@@ -58,16 +103,22 @@ __global__ void k_rmw(T* out, int iters)
 	if (s == T(12345)) out[blockIdx.x] = s;
 }
 
+template <typename T>
+T* argOf(void (*)(T*, int));
+
 template <typename K>
 void run(const char* name, K kern, int blocks, int threads, void* out)
 {
+	static void* sink = nullptr;  // a real buffer: a kernel's guard store must never see a null pointer
+	if (!sink) CHECK(hipMalloc(&sink, 1 << 20));
+	(void)out;
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
 	CHECK(hipEventCreate(&e1));
-	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, (decltype(nullptr))nullptr, 16);
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, reinterpret_cast<decltype(argOf(kern))>(sink), 16);
 	CHECK(hipDeviceSynchronize());
 	CHECK(hipEventRecord(e0));
-	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, (decltype(nullptr))nullptr, ITERS);
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, reinterpret_cast<decltype(argOf(kern))>(sink), ITERS);
 	CHECK(hipEventRecord(e1));
 	CHECK(hipEventSynchronize(e1));
 	float ms;
@@ -96,6 +147,11 @@ int main(int argc, char** argv)
 		RUNALL(float, "ds_add_f32")
 		RUNALL(unsigned int, "ds_add_u32")
 		run("rmw f64 (read+add+write) linear", k_rmw<double>, blocks, threads, nullptr);
+		run("ds_add_u64 7-lane groups", k_atomic<unsigned long long, 5>, blocks, threads, nullptr);
+		run("ds_add_u64 random base + tap", k_atomic<unsigned long long, 6>, blocks, threads, nullptr);
+		run("ds_read_b64 linear", k_read<0>, blocks, threads, nullptr);
+		run("ds_read_b64 7-lane groups", k_read<5>, blocks, threads, nullptr);
+		run("ds_read_b64 random base + tap", k_read<6>, blocks, threads, nullptr);
 	}
 	return 0;
 }
