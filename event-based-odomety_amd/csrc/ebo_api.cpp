@@ -211,6 +211,9 @@ bool mid_timestamp(int64_t a, int64_t b, int64_t& out)
 }
 
 const size_t kLdsBudget = 160 * 1024;
+// host memory that kernels read and write directly: mapped into the device's address space and
+// coherent (fine-grained), whatever HIP_HOST_COHERENT says
+const unsigned int kZeroCopyFlags = hipHostMallocMapped | hipHostMallocCoherent;
 const size_t kRedBytes = 16 * 8 * sizeof(double);
 
 size_t lds_for(int channels, int tiles, int rw, int rh)
@@ -561,9 +564,9 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 			c->pin_modes = nullptr;
 			c->pin_cap = 0;
 		}
-		hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_flows), nf * 2 * sizeof(double), hipHostMallocDefault);
-		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_out), nf * 3 * sizeof(double), hipHostMallocDefault);
-		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_modes), nf, hipHostMallocDefault);
+		hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_flows), nf * 2 * sizeof(double), kZeroCopyFlags);
+		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_out), nf * 3 * sizeof(double), kZeroCopyFlags);
+		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_modes), nf, kZeroCopyFlags);
 		rc = c->hip(e, "hipHostMalloc evaluation staging");
 		if (rc)
 		{
@@ -2448,7 +2451,7 @@ int ebo_route_events(ebo_ctx* c, int n_patches, const double* rects, const uint3
 			c->pin_route = nullptr;
 			c->pin_route_cap = 0;
 		}
-		int rc = c->hip(hipHostMalloc(&c->pin_route, need, hipHostMallocDefault), "hipHostMalloc route staging");
+		int rc = c->hip(hipHostMalloc(&c->pin_route, need, kZeroCopyFlags), "hipHostMalloc route staging");
 		if (rc)
 		{
 			return rc;
