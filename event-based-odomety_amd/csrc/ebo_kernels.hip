@@ -1698,6 +1698,39 @@ __global__ void __launch_bounds__(256) k_csort_hist(const uint64_t* __restrict__
 	}
 }
 
+// Exclusive prefix sum of one value per thread over the workgroup (wave scans by shuffles, then
+// the wave totals); tmp: at least blockDim / 64 + 1 words of LDS.  Returns the exclusive prefix,
+// total = sum over the workgroup.  Ends with the values in tmp still needed: callers barrier before
+// reusing tmp.
+__device__ __forceinline__ unsigned int block_exclusive_scan(unsigned int v, unsigned int* tmp, unsigned int& total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+	unsigned int incl = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1)
+	{
+		const unsigned int up = __shfl_up(incl, d, 64);
+		if (lane >= d)
+		{
+			incl += up;
+		}
+	}
+	if (lane == 63)
+	{
+		tmp[wave] = incl;
+	}
+	__syncthreads();
+	unsigned int before = 0;
+	total = 0;
+	for (int k = 0; k < nWaves; ++k)
+	{
+		const unsigned int t = tmp[k];
+		before += k < wave ? t : 0u;
+		total += t;
+	}
+	return before + incl - v;
+}
+
 // Exclusive scan of the bin counts (a few thousand bins: one workgroup), cursors = starts.
 __global__ void __launch_bounds__(1024) k_csort_scan(unsigned int* __restrict__ sortBins, int nBins)
 {
@@ -1712,21 +1745,12 @@ __global__ void __launch_bounds__(1024) k_csort_scan(unsigned int* __restrict__ 
 	{
 		s += counts[b];
 	}
-	part[threadIdx.x] = s;
-	__syncthreads();
+	unsigned int total;
+	unsigned int run = block_exclusive_scan(s, part, total);
 	if (threadIdx.x == 0)
 	{
-		unsigned int run = 0;
-		for (int t = 0; t < 1024; ++t)
-		{
-			const unsigned int v = part[t];
-			part[t] = run;
-			run += v;
-		}
-		starts[nBins] = run;
+		starts[nBins] = total;
 	}
-	__syncthreads();
-	unsigned int run = part[threadIdx.x];
 	for (int b = b0; b < b1; ++b)
 	{
 		starts[b] = run;
@@ -1790,20 +1814,8 @@ __global__ void __launch_bounds__(256) k_csort_scatter(const Unit* __restrict__ 
 	{
 		sum += hist[bnd];
 	}
-	part[threadIdx.x] = sum;
-	__syncthreads();
-	if (threadIdx.x == 0)
-	{
-		unsigned int run = 0;
-		for (int t = 0; t < 256; ++t)
-		{
-			const unsigned int v = part[t];
-			part[t] = run;
-			run += v;
-		}
-	}
-	__syncthreads();
-	unsigned int run = part[threadIdx.x];
+	unsigned int chunkTotal;
+	unsigned int run = block_exclusive_scan(sum, part, chunkTotal);  // (a serial scan of the 256 partials by one thread was 45 % of this kernel)
 	for (int bnd = s0; bnd < s1; ++bnd)
 	{
 		const unsigned int h = hist[bnd];
@@ -1821,6 +1833,9 @@ __global__ void __launch_bounds__(256) k_csort_scatter(const Unit* __restrict__ 
 	{
 		if (dst[k] != 0xFFFFFFFFu)
 		{
+			// (one LDS atomic per distinct band of the wave -- ballot, leader add, prefix count -- was
+			// tried for these ranks and for the histograms: C3 0.34 -> 0.23 ms, but C4 0.32 -> 0.49 ms,
+			// where a wave's events spread over ~12 of the 180 four-row bands; C3 runs impl 1 anyway)
 			const unsigned int bnd = dst[k] / bandPx;
 			const unsigned int at = atomicAdd(&lcur[bnd], 1u);
 			staged[at] = dst[k];
