@@ -2482,7 +2482,7 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 			return -2;
 		}
 	}
-	hipLaunchKernelGGL(k_bucket_scan, dim3((L.n_windows + 63) / 64), dim3(64), 0, s, raw, L.d_offsets,
+	hipLaunchKernelGGL(k_bucket_scan, dim3(L.n_windows), dim3(256), 0, s, raw, L.d_offsets,
 					   L.n_windows, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.min_events, L.d_units,
 					   L.d_unit_tref, L.d_win_tref, L.d_flag, L.c);
 	if (check_launch())
