@@ -2,152 +2,9 @@
 // kernel launches and the extern "C" entry points declared in include/ebo.h.
 // There is no CPU compute path here: every objective value, Jacobian, solved flow
 // and count image comes from the HIP kernels in ebo_kernels.hip.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
+#include "ebo_ctx.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <thread>
-
-#include "../../include/ebo.h"
-#include "ebo_internal.h"
-#include "field_tv.h"
-#include "host_lm.h"
-
-using namespace ebo;
-
-namespace
-{
-thread_local std::string g_create_error;
-
-size_t env_size(const char* name, size_t dflt)
-{
-	const char* v = std::getenv(name);
-	if (!v || !*v)
-	{
-		return dflt;
-	}
-	return static_cast<size_t>(std::strtoull(v, nullptr, 10));
-}
-
-struct WindowInfo
-{
-	int64_t t_ref;
-	uint64_t n_events;
-};
-}  // namespace
-
-struct ebo_ctx
-{
-	ebo_params prm;
-	int npx = 0, npy = 0, P = 0;
-	hipStream_t stream = nullptr;
-	bool own_stream = false;
-	std::string err;
-
-	size_t cap_events = 0;
-	int cap_windows = 0;
-	int n_windows = 0;
-
-	uint64_t* d_events = nullptr;
-	Unit* d_units = nullptr;
-	double* d_flows = nullptr;
-	double* d_out = nullptr;
-	double* d_partials = nullptr;
-	size_t partials_cap = 0;
-	int32_t* d_counts = nullptr;
-	double* d_image = nullptr;
-	void* d_aux = nullptr;
-	size_t aux_cap = 0;
-	unsigned char* d_modes = nullptr;        // per-flow-slot evaluation modes of a lock-step solve
-	size_t modes_cap = 0;
-	const unsigned char* modes_active = nullptr;  // non-null only inside eval_host(modes)
-	double2* d_opt_grid = nullptr;   // Optimizer::setGrad's interleaved gradient grid [H][W]
-	bool opt_grid_valid = false;
-	void* d_opt = nullptr;           // scratch of ebo_optimizer_eval / _solve
-	size_t opt_cap = 0;
-	unsigned long long* d_count_ovf = nullptr;  // k_count_bands' overflow list / k_csort_* sorted list
-	size_t count_ovf_cap = 0;
-	unsigned int* d_count_bins = nullptr;       // k_csort_*: counts, starts, cursors per (window, band)
-	size_t count_bins_cap = 0;                  // in bins
-	int32_t* d_stats = nullptr;
-	void* d_scratch = nullptr;  // patch-integrate staging
-	size_t scratch_cap = 0;
-	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
-	size_t edge_scratch_cap = 0;
-	void* d_field = nullptr;         // motion field of ebo_init_motion_field (+ its staging)
-	size_t field_cap = 0;
-	bool field_valid = false;
-	const int* d_field_fixed = nullptr;  // fixed points of that field, [field_nfixed][2]
-	int field_nfixed = 0;
-	void* d_tvf = nullptr;           // workspace of ebo_interpolate_motion_field
-	size_t tvf_cap = 0;
-	void* comm = nullptr;            // ncclComm_t of ebo_comm_init
-	int comm_rank = 0, comm_size = 1;
-	void* d_raw = nullptr;           // raw 24-byte events staged for device bucketing
-	void* d_bucket = nullptr;        // bucketing scratch
-	size_t bucket_cap = 0;
-
-	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window
-	std::vector<int64_t> unit_tref;
-	std::vector<WindowInfo> windows;
-	std::vector<uint64_t> h_packed;
-	// pinned, device-visible staging of one evaluation round (flows in, (r, J0, J1) out, modes):
-	// small rounds let the kernels read and write it directly (no copy packets at all), large
-	// ones copy from/to it at DMA speed
-	uint32_t* d_route_xy = nullptr;  // ebo_route_set_events: x:16 | y:16 per event of the chunk
-	size_t route_cap = 0;
-	size_t route_n = 0;
-	void* pin_route = nullptr;       // pinned, device-visible arguments and results of ebo_route_events
-	size_t pin_route_cap = 0;
-	void* pin_bucket = nullptr;      // pinned mirror of the bucketing results (offsets in; units, reference times, flag out)
-	size_t pin_bucket_cap = 0;
-	double* pin_flows = nullptr;
-	double* pin_out = nullptr;
-	unsigned char* pin_modes = nullptr;
-	size_t pin_cap = 0;
-
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	int max_rw = 0, max_rh = 0;
-	int grid_max_rw = 0, grid_max_rh = 0;
-	int custom_n = 0;  // > 0: units were loaded by ebo_set_patches (arbitrary rects)
-
-	int cur_patches() const { return custom_n ? custom_n : P; }
-	size_t n_flows() const
-	{
-		return custom_n ? static_cast<size_t>(custom_n) : static_cast<size_t>(n_windows) * P;
-	}
-	size_t unit_index(int window, int patch) const
-	{
-		return custom_n ? static_cast<size_t>(patch) : static_cast<size_t>(window) * (P + 1) + patch;
-	}
-
-	int fail(int code, const std::string& msg)
-	{
-		err = msg;
-		return code;
-	}
-	int hip(hipError_t e, const char* what)
-	{
-		if (e == hipSuccess)
-		{
-			return EBO_OK;
-		}
-		err = std::string(what) + ": " + hipGetErrorString(e);
-		return EBO_ERR_HIP;
-	}
-};
-
-namespace
+namespace ebo_host
 {
 EvalConsts make_consts(const ebo_ctx* c)
 {
@@ -210,10 +67,10 @@ bool mid_timestamp(int64_t a, int64_t b, int64_t& out)
 	return true;
 }
 
-const size_t kLdsBudget = 160 * 1024;
+extern const size_t kLdsBudget = 160 * 1024;
 // host memory that kernels read and write directly: mapped into the device's address space and
 // coherent (fine-grained), whatever HIP_HOST_COHERENT says
-const unsigned int kZeroCopyFlags = hipHostMallocMapped | hipHostMallocCoherent;
+extern const unsigned int kZeroCopyFlags = hipHostMallocMapped | hipHostMallocCoherent;
 const size_t kRedBytes = 16 * 8 * sizeof(double);
 
 size_t lds_for(int channels, int tiles, int rw, int rh)
@@ -1155,7 +1012,12 @@ int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_o
 	return EBO_OK;
 }
 
-}  // namespace
+}  // namespace ebo_host
+
+namespace ebo_host
+{
+thread_local std::string g_create_error;  // what ebo_last_error(NULL) reports
+}
 
 extern "C" {
 
@@ -2227,1193 +2089,6 @@ int ebo_compensate_events_contrast(ebo_ctx* c, const ebo_event* ev, size_t n,
 		rc = ebo_count_image(c, EBO_COUNT_WARPED, flows_out, image_out);
 	}
 	return rc;
-}
-
-static int patch_integrate_common(ebo_ctx* c, const ebo_event* ev, const size_t* offsets,
-								  int n_patches, const double* rects, const double* traj,
-								  const int64_t* mid_time, const size_t* nabla_offsets,
-								  double* nabla, int64_t* current_ts, int64_t* time_last_update,
-								  int32_t* updated)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (!ev || !offsets || n_patches <= 0 || !rects || !nabla_offsets || !nabla)
-	{
-		return c->fail(EBO_ERR_ARG, "null argument to patch integrate");
-	}
-	const bool mc = traj != nullptr;
-	if (mc && (!mid_time || !updated))
-	{
-		return c->fail(EBO_ERR_ARG, "null mid_time/updated");
-	}
-	(void)hipSetDevice(c->prm.device);
-	const size_t e0 = offsets[0];
-	const size_t total = offsets[n_patches] - e0;
-	if (total >= (1ull << 32))
-	{
-		return c->fail(EBO_ERR_ARG, "too many events");
-	}
-	std::vector<uint64_t> packed(total);
-	std::vector<uint32_t> off32(n_patches + 1);
-	std::vector<double> tr(mc ? static_cast<size_t>(n_patches) * 4 : 0);
-	std::vector<uint64_t> noff(n_patches);
-	size_t nablaEnd = 0;
-	for (int p = 0; p < n_patches; ++p)
-	{
-		const size_t a = offsets[p], b = offsets[p + 1];
-		if (b < a)
-		{
-			return c->fail(EBO_ERR_ARG, "offsets must be non-decreasing");
-		}
-		off32[p] = static_cast<uint32_t>(a - e0);
-		const double rw = rects[4 * p + 2], rh = rects[4 * p + 3];
-		const int cols = static_cast<int>(rw), rows = static_cast<int>(rh);
-		if (cols <= 0 || rows <= 0 || static_cast<size_t>(cols) * rows > 16384)
-		{
-			return c->fail(EBO_ERR_UNSUPPORTED, "patch image must have 1..16384 pixels");
-		}
-		noff[p] = nabla_offsets[p];
-		nablaEnd = std::max(nablaEnd, nabla_offsets[p] + static_cast<size_t>(cols) * rows);
-		int64_t tref = 0;
-		bool pass = true;
-		if (mc)
-		{
-			// patch.cpp:94-100
-			const int64_t preT = static_cast<int64_t>(traj[6 * p + 2]);
-			const int64_t lastT = static_cast<int64_t>(traj[6 * p + 5]);
-			const double halfD = static_cast<double>(lastT - preT) * 0.5;
-			if (!(halfD > -2147483648.0 && halfD < 2147483648.0))
-			{
-				return c->fail(EBO_ERR_RANGE, "trajectory time step outside int32 microseconds");
-			}
-			const int64_t half = static_cast<int64_t>(static_cast<int32_t>(halfD));
-			tref = mid_time[p];
-			pass = (b > a) && (lastT + half >= tref) && (preT < tref);
-			tr[4 * p + 0] = traj[6 * p + 3] - traj[6 * p + 0];
-			tr[4 * p + 1] = traj[6 * p + 4] - traj[6 * p + 1];
-			tr[4 * p + 2] = static_cast<double>(lastT - preT);
-			tr[4 * p + 3] = pass ? 1.0 : 0.0;
-			updated[p] = pass ? 1 : 0;
-		}
-		else if (b > a)
-		{
-			// patch.cpp:78-83
-			int64_t mid;
-			if (!mid_timestamp(ev[a].t_us, ev[b - 1].t_us, mid))
-			{
-				return c->fail(EBO_ERR_RANGE, "patch mid-time outside int32 microseconds");
-			}
-			if (current_ts) current_ts[p] = mid;
-			if (time_last_update)
-			{
-				time_last_update[p] = static_cast<int64_t>(static_cast<int32_t>(ev[b - 1].t_us));
-			}
-		}
-		for (size_t i = a; i < b; ++i)
-		{
-			if (ev[i].x < kCoordMin || ev[i].x > kCoordMax || ev[i].y < kCoordMin || ev[i].y > kCoordMax)
-			{
-				return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
-			}
-			const int64_t dt = mc ? (tref - ev[i].t_us) : 0;
-			if (dt < INT32_MIN || dt > INT32_MAX)
-			{
-				return c->fail(EBO_ERR_RANGE, "event time further than 2^31 us from mid time");
-			}
-			packed[i - e0] = static_cast<uint64_t>(pack_lo(ev[i].x, ev[i].y, ev[i].sign > 0)) |
-							 (static_cast<uint64_t>(static_cast<uint32_t>(static_cast<int32_t>(dt))) << 32);
-		}
-	}
-	off32[n_patches] = static_cast<uint32_t>(total);
-	// staging layout: events | offsets | rects | traj | nabla offsets | nabla
-	auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-	const size_t bEv = align(total * 8), bOff = align(off32.size() * 4), bRect = align(static_cast<size_t>(n_patches) * 32);
-	const size_t bTraj = align(tr.size() * 8), bNoff = align(noff.size() * 8), bNabla = align(nablaEnd * 8);
-	int rc = ensure_scratch(c, bEv + bOff + bRect + bTraj + bNoff + bNabla);
-	if (rc)
-	{
-		return rc;
-	}
-	char* base = static_cast<char*>(c->d_scratch);
-	char* dEv = base;
-	char* dOff = dEv + bEv;
-	char* dRect = dOff + bOff;
-	char* dTraj = dRect + bRect;
-	char* dNoff = dTraj + bTraj;
-	char* dNabla = dNoff + bNoff;
-	hipError_t e = hipSuccess;
-	if (total) e = hipMemcpyAsync(dEv, packed.data(), total * 8, hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(dOff, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(dRect, rects, static_cast<size_t>(n_patches) * 32, hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess && mc) e = hipMemcpyAsync(dTraj, tr.data(), tr.size() * 8, hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(dNoff, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, c->stream);
-	// R6 leaves images of patches that fail the time test untouched: start from the caller's data
-	if (e == hipSuccess && mc) e = hipMemcpyAsync(dNabla, nabla, nablaEnd * 8, hipMemcpyHostToDevice, c->stream);
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "H2D patch data");
-	}
-	PatchIntLaunch L;
-	L.d_events = reinterpret_cast<const uint64_t*>(dEv);
-	L.d_offsets = reinterpret_cast<const uint32_t*>(dOff);
-	L.d_rects = reinterpret_cast<const double*>(dRect);
-	L.d_traj = mc ? reinterpret_cast<const double*>(dTraj) : nullptr;
-	L.d_nabla_off = reinterpret_cast<const uint64_t*>(dNoff);
-	L.d_nabla = reinterpret_cast<double*>(dNabla);
-	L.n_patches = n_patches;
-	if (launch_patch_integrate(L, c->stream))
-	{
-		return c->hip(hipGetLastError(), "patch integrate launch");
-	}
-	rc = c->hip(hipMemcpyAsync(nabla, dNabla, nablaEnd * 8, hipMemcpyDeviceToHost, c->stream), "D2H nabla");
-	if (rc)
-	{
-		return rc;
-	}
-	return c->hip(hipStreamSynchronize(c->stream), "sync");
-}
-
-int ebo_route_set_events(ebo_ctx* c, const ebo_event* ev, size_t n)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if ((!ev && n > 0) || n > 0xFFFFFFF0u)
-	{
-		return c->fail(EBO_ERR_ARG, "null events or more than 2^32 events in a chunk");
-	}
-	(void)hipSetDevice(c->prm.device);
-	c->route_n = 0;
-	if (n > c->route_cap)
-	{
-		hipFree(c->d_route_xy);
-		c->d_route_xy = nullptr;
-		c->route_cap = 0;
-		int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_route_xy), n * sizeof(uint32_t)), "hipMalloc route events");
-		if (rc)
-		{
-			return rc;
-		}
-		c->route_cap = n;
-	}
-	std::vector<uint32_t> xy(n);
-	for (size_t i = 0; i < n; ++i)
-	{
-		if (ev[i].x < kCoordMin || ev[i].x > kCoordMax || ev[i].y < kCoordMin || ev[i].y > kCoordMax)
-		{
-			return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
-		}
-		xy[i] = (static_cast<uint32_t>(ev[i].x) & 0xFFFFu) | (static_cast<uint32_t>(ev[i].y) << 16);
-	}
-	if (n > 0)
-	{
-		int rc = c->hip(hipMemcpy(c->d_route_xy, xy.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice), "H2D route events");
-		if (rc)
-		{
-			return rc;
-		}
-	}
-	c->route_n = n;
-	return EBO_OK;
-}
-
-int ebo_route_events(ebo_ctx* c, int n_patches, const double* rects, const uint32_t* start, const uint32_t* max_take,
-					 uint32_t cap, uint32_t* out_index, uint32_t* out_count, uint32_t* out_next)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (n_patches < 0 || (n_patches > 0 && (!rects || !start || !max_take || !out_count || !out_next)) ||
-		(cap > 0 && n_patches > 0 && !out_index))
-	{
-		return c->fail(EBO_ERR_ARG, "null argument");
-	}
-	if (n_patches == 0)
-	{
-		return EBO_OK;
-	}
-	(void)hipSetDevice(c->prm.device);
-	// one pinned block the kernel reads its arguments from and writes its results to (all small:
-	// no copy packets, one launch + one sync): rects | start | take | count | next | index
-	const size_t np = static_cast<size_t>(n_patches);
-	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-	const size_t bR = al(np * 32), bU = al(np * 4), bI = al(np * cap * 4 + 4);
-	const size_t need = bR + 4 * bU + bI;
-	if (need > c->pin_route_cap)
-	{
-		if (c->pin_route)
-		{
-			(void)hipHostFree(c->pin_route);
-			c->pin_route = nullptr;
-			c->pin_route_cap = 0;
-		}
-		int rc = c->hip(hipHostMalloc(&c->pin_route, need, kZeroCopyFlags), "hipHostMalloc route staging");
-		if (rc)
-		{
-			return rc;
-		}
-		c->pin_route_cap = need;
-	}
-	char* pin = static_cast<char*>(c->pin_route);
-	std::memcpy(pin, rects, np * 32);
-	std::memcpy(pin + bR, start, np * 4);
-	std::memcpy(pin + bR + bU, max_take, np * 4);
-	RouteLaunch L;
-	L.d_xy = c->d_route_xy;
-	L.n_events = static_cast<uint32_t>(c->route_n);
-	L.n_patches = n_patches;
-	L.d_rects = reinterpret_cast<const double*>(pin);
-	L.d_start = reinterpret_cast<const uint32_t*>(pin + bR);
-	L.d_take = reinterpret_cast<const uint32_t*>(pin + bR + bU);
-	L.d_count = reinterpret_cast<uint32_t*>(pin + bR + 2 * bU);
-	L.d_next = reinterpret_cast<uint32_t*>(pin + bR + 3 * bU);
-	L.d_index = reinterpret_cast<uint32_t*>(pin + bR + 4 * bU);
-	L.cap = cap;
-	if (launch_route(L, c->stream))
-	{
-		return c->hip(hipGetLastError(), "route launch");
-	}
-	int rc = c->hip(hipStreamSynchronize(c->stream), "sync");
-	if (rc)
-	{
-		return rc;
-	}
-	std::memcpy(out_count, L.d_count, np * 4);
-	std::memcpy(out_next, L.d_next, np * 4);
-	for (size_t p = 0; p < np; ++p)
-	{
-		std::memcpy(out_index + p * cap, L.d_index + p * cap, static_cast<size_t>(out_count[p]) * 4);
-	}
-	return EBO_OK;
-}
-
-int ebo_patch_integrate(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_patches,
-						const double* rects, const size_t* nabla_offsets, double* nabla,
-						int64_t* current_ts, int64_t* time_last_update)
-{
-	return patch_integrate_common(c, ev, offsets, n_patches, rects, nullptr, nullptr,
-								  nabla_offsets, nabla, current_ts, time_last_update, nullptr);
-}
-
-int ebo_patch_integrate_mc(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_patches,
-						   const double* rects, const double* traj, const int64_t* mid_time,
-						   const size_t* nabla_offsets, double* nabla, int32_t* updated)
-{
-	if (c && !traj)
-	{
-		return c->fail(EBO_ERR_ARG, "null trajectory");
-	}
-	return patch_integrate_common(c, ev, offsets, n_patches, rects, traj, mid_time, nabla_offsets,
-								  nabla, nullptr, nullptr, updated);
-}
-
-// FeatureDetector::initMotionField (feature_detector.cpp:53-142).
-int ebo_init_motion_field(ebo_ctx* c, int64_t timestamp, int use_average, int n_patches,
-						  const size_t* traj_offsets, const double* traj_xy, const int64_t* traj_t,
-						  float* field_out, int32_t* n_fixed, int32_t* fixed_xy)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (n_patches < 0 || (n_patches > 0 && (!traj_offsets || !traj_xy || !traj_t)))
-	{
-		return c->fail(EBO_ERR_ARG, "null trajectory arrays");
-	}
-	(void)hipSetDevice(c->prm.device);
-	const int w = c->prm.image_w, h = c->prm.image_h;
-	const size_t npx = static_cast<size_t>(w) * h;
-	const size_t nSamples = n_patches > 0 ? traj_offsets[n_patches] : 0;
-	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-	const size_t bField = al(npx * 2 * sizeof(float));
-	const size_t bOff = al((static_cast<size_t>(n_patches) + 1) * 8), bXY = al(nSamples * 16), bT = al(nSamples * 8);
-	const size_t bFix = al(static_cast<size_t>(std::max(n_patches, 1)) * 8);
-	const size_t need = bField + bOff + bXY + bT + bFix + 512;
-	if (need > c->field_cap)
-	{
-		if (c->d_field)
-		{
-			hipFree(c->d_field);
-			c->d_field = nullptr;
-			c->field_cap = 0;
-		}
-		int rc = c->hip(hipMalloc(&c->d_field, need), "hipMalloc motion field");
-		if (rc)
-		{
-			return rc;
-		}
-		c->field_cap = need;
-	}
-	char* base = static_cast<char*>(c->d_field);
-	FieldLaunch L;
-	L.w = w;
-	L.h = h;
-	L.scale = c->prm.scale;
-	L.use_average = use_average ? 1 : 0;
-	L.n_patches = n_patches;
-	L.d_field = reinterpret_cast<float*>(base);
-	L.d_off = reinterpret_cast<unsigned long long*>(base + bField);
-	L.d_xy = reinterpret_cast<double*>(base + bField + bOff);
-	L.d_t = reinterpret_cast<long long*>(base + bField + bOff + bXY);
-	L.d_fixed = reinterpret_cast<int*>(base + bField + bOff + bXY + bT);
-	L.d_avg = reinterpret_cast<double*>(base + bField + bOff + bXY + bT + bFix);
-	L.d_nfixed = reinterpret_cast<int*>(base + bField + bOff + bXY + bT + bFix + 256);
-	L.timestamp = timestamp;
-	std::vector<unsigned long long> off64(static_cast<size_t>(n_patches) + 1, 0ull);
-	for (int k = 0; k <= n_patches && n_patches > 0; ++k)
-	{
-		off64[k] = traj_offsets[k];
-	}
-	hipError_t e = hipMemcpyAsync(const_cast<unsigned long long*>(L.d_off), off64.data(), off64.size() * 8,
-								  hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess && nSamples)
-	{
-		e = hipMemcpyAsync(const_cast<double*>(L.d_xy), traj_xy, nSamples * 16, hipMemcpyHostToDevice, c->stream);
-	}
-	if (e == hipSuccess && nSamples)
-	{
-		e = hipMemcpyAsync(const_cast<long long*>(L.d_t), traj_t, nSamples * 8, hipMemcpyHostToDevice, c->stream);
-	}
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "H2D trajectories");
-	}
-	if (launch_init_field(L, c->stream))
-	{
-		return c->hip(hipGetLastError(), "motion field launch");
-	}
-	int nf = 0;
-	if (field_out)
-	{
-		e = hipMemcpyAsync(field_out, L.d_field, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-	}
-	if (e == hipSuccess)
-	{
-		e = hipMemcpyAsync(&nf, L.d_nfixed, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-	}
-	if (e == hipSuccess)
-	{
-		e = hipStreamSynchronize(c->stream);
-	}
-	if (e == hipSuccess && fixed_xy && nf > 0)
-	{
-		e = hipMemcpy(fixed_xy, L.d_fixed, static_cast<size_t>(nf) * 8, hipMemcpyDeviceToHost);
-	}
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "D2H motion field");
-	}
-	if (n_fixed)
-	{
-		*n_fixed = nf;
-	}
-	c->field_valid = true;
-	c->d_field_fixed = L.d_fixed;
-	c->field_nfixed = nf;
-	return EBO_OK;
-}
-
-int ebo_interpolate_motion_field(ebo_ctx* c, int use_l1, const ebo_solver_opts* opts, float* field_out,
-								 ebo_summary* summary, int32_t* cg_iterations)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (!c->field_valid)
-	{
-		return c->fail(EBO_ERR_STATE, "ebo_interpolate_motion_field needs ebo_init_motion_field first");
-	}
-	(void)hipSetDevice(c->prm.device);
-	const int w = c->prm.image_w, h = c->prm.image_h;
-	if (w < 2 || h < 2)
-	{
-		return c->fail(EBO_ERR_ARG, "image too small for the TV problem");
-	}
-	// a fixed point at pixel (w-1, h-1) is no parameter block of the reference's problem
-	// (feature_detector.cpp:170-204): Ceres aborts in IsParameterBlockConstant (:208)
-	std::vector<int32_t> fixed(static_cast<size_t>(c->field_nfixed) * 2);
-	if (c->field_nfixed > 0)
-	{
-		int rc = c->hip(hipMemcpyAsync(fixed.data(), c->d_field_fixed, fixed.size() * sizeof(int32_t),
-									   hipMemcpyDeviceToHost, c->stream), "D2H fixed points");
-		if (rc == EBO_OK)
-		{
-			rc = c->hip(hipStreamSynchronize(c->stream), "sync");
-		}
-		if (rc)
-		{
-			return rc;
-		}
-		for (int i = 0; i < c->field_nfixed; ++i)
-		{
-			if (fixed[2 * i] == w - 1 && fixed[2 * i + 1] == h - 1)
-			{
-				return c->fail(EBO_ERR_RANGE, "fixed point at the last pixel: not a parameter of the TV problem");
-			}
-		}
-	}
-	const size_t need = tvf_workspace_bytes(w, h);
-	if (need > c->tvf_cap)
-	{
-		if (c->d_tvf)
-		{
-			hipFree(c->d_tvf);
-			c->d_tvf = nullptr;
-			c->tvf_cap = 0;
-		}
-		int rc = c->hip(hipMalloc(&c->d_tvf, need), "hipMalloc TV workspace");
-		if (rc)
-		{
-			return rc;
-		}
-		c->tvf_cap = need;
-	}
-	ebo_solver_opts o;
-	if (opts)
-	{
-		o = *opts;
-	}
-	else
-	{
-		// ceres::Solver::Options defaults with feature_detector.cpp:216-222 applied
-		ebo_default_solver(&o);
-		o.use_nonmonotonic = 0;
-		o.function_tolerance = 1e-6;
-		o.gradient_tolerance = 1e-10;
-		o.parameter_tolerance = 1e-8;
-	}
-	FieldTvStats st;
-	int rc = field_tv_solve(w, h, static_cast<float*>(c->d_field), c->d_field_fixed, c->field_nfixed,
-							use_l1 != 0, o, c->d_tvf, c->stream, &st, &c->err);
-	if (rc)
-	{
-		return rc;
-	}
-	if (summary)
-	{
-		summary->iterations = st.iterations;
-		summary->num_evals_cost = st.evals_cost;
-		summary->num_evals_jac = st.evals_jac;
-		summary->termination = st.termination;
-		summary->initial_cost = st.initial_cost;
-		summary->final_cost = st.final_cost;
-	}
-	if (cg_iterations)
-	{
-		*cg_iterations = st.cg_iterations;
-	}
-	if (field_out)
-	{
-		rc = c->hip(hipMemcpy(field_out, c->d_field, static_cast<size_t>(w) * h * 2 * sizeof(float),
-							  hipMemcpyDeviceToHost), "D2H motion field");
-		if (rc)
-		{
-			return rc;
-		}
-	}
-	return st.termination == 2 ? c->fail(EBO_ERR_SOLVER, "field TV solve failed") : EBO_OK;
-}
-
-// ---- per-feature tracker objective ---------------------------------------
-void ebo_optimizer_default_solver(ebo_solver_opts* o)
-{
-	if (!o)
-	{
-		return;
-	}
-	ebo_default_solver(o);
-	o->max_num_iterations = 10;  // OptimizerParams::maxNumIterations
-	o->use_nonmonotonic = 1;     // optimizer.cpp:110
-	o->function_tolerance = 1e-6;
-	o->gradient_tolerance = 1e-10;
-	o->parameter_tolerance = 1e-8;
-	o->mode = EBO_SOLVE_INDEPENDENT;
-}
-
-int ebo_optimizer_set_grad(ebo_ctx* c, const double* grad_x, const double* grad_y)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (!grad_x || !grad_y)
-	{
-		return c->fail(EBO_ERR_ARG, "null gradient image");
-	}
-	(void)hipSetDevice(c->prm.device);
-	const size_t n = static_cast<size_t>(c->prm.image_w) * c->prm.image_h;
-	int rc = EBO_OK;
-	if (!c->d_opt_grid)
-	{
-		rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_opt_grid), n * sizeof(double2)), "hipMalloc gradient grid");
-		if (rc)
-		{
-			return rc;
-		}
-	}
-	rc = ensure_aux(c, 2 * n * sizeof(double));
-	if (rc)
-	{
-		return rc;
-	}
-	double* stage = static_cast<double*>(c->d_aux);
-	hipError_t e = hipMemcpyAsync(stage, grad_x, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess)
-	{
-		e = hipMemcpyAsync(stage + n, grad_y, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
-	}
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "H2D gradient images");
-	}
-	if (launch_optimizer_interleave(stage, stage + n, n, c->d_opt_grid, c->stream))
-	{
-		return c->hip(hipGetLastError(), "gradient grid launch");
-	}
-	rc = c->hip(hipStreamSynchronize(c->stream), "sync");
-	c->opt_grid_valid = rc == EBO_OK;
-	return rc;
-}
-
-namespace
-{
-struct OptBuffers
-{
-	OptPatch* patches;
-	double* nabla_in;
-	double* nabla;
-	double* x;
-	double* stats;
-	double* res;
-	double* jac_pose;
-	double* jac_flow;
-	size_t total;
-	int max_pixels;
-};
-
-// Validates the rects, uploads patches / nabla / parameters; normalize: nabla is the raw
-// integrated nabla and is normalised on the device (Patch::getNormalizedIntegratedNabla).
-int optimizer_stage(ebo_ctx* c, int n, const double* rects, const double* nabla, int normalize,
-					const double* poses, const double* flow_dirs, bool wantRes, bool wantJac, OptBuffers& B)
-{
-	if (!c->opt_grid_valid)
-	{
-		return c->fail(EBO_ERR_STATE, "ebo_optimizer_set_grad has not been called");
-	}
-	if (n < 0 || (n > 0 && (!rects || !nabla || !poses || !flow_dirs)))
-	{
-		return c->fail(EBO_ERR_ARG, "bad argument to the optimizer");
-	}
-	std::vector<OptPatch> hp(n);
-	size_t total = 0;
-	int maxPx = 1;
-	for (int i = 0; i < n; ++i)
-	{
-		const double w = rects[4 * i + 2], h = rects[4 * i + 3];
-		if (!(w >= 1.0) || !(h >= 1.0) || w > 4096.0 || h > 4096.0 || !std::isfinite(rects[4 * i]) ||
-			!std::isfinite(rects[4 * i + 1]))
-		{
-			return c->fail(EBO_ERR_ARG, "bad patch rect");
-		}
-		hp[i].rx = rects[4 * i];
-		hp[i].ry = rects[4 * i + 1];
-		hp[i].pw = static_cast<int>(w);
-		hp[i].ph = static_cast<int>(h);
-		hp[i].off = total;
-		const int px = hp[i].pw * hp[i].ph;
-		if (px > 3000)
-		{
-			return c->fail(EBO_ERR_UNSUPPORTED, "tracked patch larger than 3000 pixels");
-		}
-		maxPx = std::max(maxPx, px);
-		total += static_cast<size_t>(px);
-	}
-	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-	const size_t bPatch = al(static_cast<size_t>(n) * sizeof(OptPatch)), bVec = al(total * 8);
-	const size_t bX = al(static_cast<size_t>(n) * 5 * 8), bStats = al(static_cast<size_t>(n) * 8 * 8);
-	const size_t need = bPatch + 2 * bVec + bX + bStats + (wantRes ? bVec : 0) + (wantJac ? 5 * bVec : 0) + 256;
-	(void)hipSetDevice(c->prm.device);
-	if (need > c->opt_cap)
-	{
-		if (c->d_opt)
-		{
-			hipFree(c->d_opt);
-			c->d_opt = nullptr;
-			c->opt_cap = 0;
-		}
-		int rc = c->hip(hipMalloc(&c->d_opt, need), "hipMalloc optimizer scratch");
-		if (rc)
-		{
-			return rc;
-		}
-		c->opt_cap = need;
-	}
-	char* b = static_cast<char*>(c->d_opt);
-	B.patches = reinterpret_cast<OptPatch*>(b);
-	b += bPatch;
-	B.nabla_in = reinterpret_cast<double*>(b);
-	b += bVec;
-	B.nabla = reinterpret_cast<double*>(b);
-	b += bVec;
-	B.x = reinterpret_cast<double*>(b);
-	b += bX;
-	B.stats = reinterpret_cast<double*>(b);
-	b += bStats;
-	B.res = wantRes ? reinterpret_cast<double*>(b) : nullptr;
-	b += wantRes ? bVec : 0;
-	B.jac_pose = wantJac ? reinterpret_cast<double*>(b) : nullptr;
-	b += wantJac ? 4 * bVec : 0;
-	B.jac_flow = wantJac ? reinterpret_cast<double*>(b) : nullptr;
-	B.total = total;
-	B.max_pixels = maxPx;
-	if (n == 0)
-	{
-		return EBO_OK;
-	}
-	std::vector<double> hx(static_cast<size_t>(n) * 5);
-	for (int i = 0; i < n; ++i)
-	{
-		for (int k = 0; k < 4; ++k)
-		{
-			hx[5 * i + k] = poses[4 * i + k];
-		}
-		hx[5 * i + 4] = flow_dirs[i];
-	}
-	hipError_t e = hipMemcpyAsync(B.patches, hp.data(), static_cast<size_t>(n) * sizeof(OptPatch), hipMemcpyHostToDevice, c->stream);
-	if (e == hipSuccess)
-	{
-		e = hipMemcpyAsync(normalize ? B.nabla_in : B.nabla, nabla, total * 8, hipMemcpyHostToDevice, c->stream);
-	}
-	if (e == hipSuccess)
-	{
-		e = hipMemcpyAsync(B.x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice, c->stream);
-	}
-	if (e == hipSuccess)
-	{
-		e = hipStreamSynchronize(c->stream);  // hp / hx are locals
-	}
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "H2D optimizer inputs");
-	}
-	if (normalize && launch_optimizer_normalize(B.patches, n, B.nabla_in, B.nabla, c->stream))
-	{
-		return c->hip(hipGetLastError(), "nabla normalisation launch");
-	}
-	return EBO_OK;
-}
-
-OptLaunch optimizer_launch(const ebo_ctx* c, int n, const OptBuffers& B)
-{
-	OptLaunch L;
-	std::memset(&L, 0, sizeof(L));
-	L.d_grid = c->d_opt_grid;
-	L.img_w = c->prm.image_w;
-	L.img_h = c->prm.image_h;
-	L.d_patches = B.patches;
-	L.n_patches = n;
-	L.max_pixels = B.max_pixels;
-	L.d_nabla = B.nabla;
-	L.d_x = B.x;
-	L.d_res = B.res;
-	L.d_jac_pose = B.jac_pose;
-	L.d_jac_flow = B.jac_flow;
-	L.d_stats = B.stats;
-	return L;
-}
-}  // namespace
-
-int ebo_optimizer_eval(ebo_ctx* c, int n, const double* rects, const double* nabla, const double* poses,
-					   const double* flow_dirs, double* residuals, double* jac_pose, double* jac_flow)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (!residuals || ((jac_pose == nullptr) != (jac_flow == nullptr)))
-	{
-		return c->fail(EBO_ERR_ARG, "residuals are required; the two Jacobians come together");
-	}
-	OptBuffers B;
-	int rc = optimizer_stage(c, n, rects, nabla, 0, poses, flow_dirs, true, jac_pose != nullptr, B);
-	if (rc || n == 0)
-	{
-		return rc;
-	}
-	OptLaunch L = optimizer_launch(c, n, B);
-	if (launch_optimizer_eval(L, c->stream))
-	{
-		return c->hip(hipGetLastError(), "optimizer evaluation launch");
-	}
-	hipError_t e = hipMemcpyAsync(residuals, B.res, B.total * 8, hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess && jac_pose)
-	{
-		e = hipMemcpyAsync(jac_pose, B.jac_pose, B.total * 4 * 8, hipMemcpyDeviceToHost, c->stream);
-	}
-	if (e == hipSuccess && jac_flow)
-	{
-		e = hipMemcpyAsync(jac_flow, B.jac_flow, B.total * 8, hipMemcpyDeviceToHost, c->stream);
-	}
-	if (e == hipSuccess)
-	{
-		e = hipStreamSynchronize(c->stream);
-	}
-	return c->hip(e, "D2H optimizer results");
-}
-
-int ebo_optimizer_solve(ebo_ctx* c, int n, const double* rects, const double* nabla, int normalize, double huber,
-						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	ebo_solver_opts o;
-	if (opts)
-	{
-		o = *opts;
-		o.mode = EBO_SOLVE_INDEPENDENT;
-		int rc = check_solver_opts(c, &o);
-		if (rc)
-		{
-			return rc;
-		}
-	}
-	else
-	{
-		ebo_optimizer_default_solver(&o);
-	}
-	if (!(huber > 0.0))
-	{
-		return c->fail(EBO_ERR_ARG, "the Huber parameter must be positive");
-	}
-	OptBuffers B;
-	int rc = optimizer_stage(c, n, rects, nabla, normalize, poses, flow_dirs, false, false, B);
-	if (rc || n == 0)
-	{
-		return rc;
-	}
-	OptLaunch L = optimizer_launch(c, n, B);
-	L.huber = huber;
-	L.s = make_solve_consts(&o);
-	if (launch_optimizer_solve(L, c->stream))
-	{
-		return c->hip(hipGetLastError(), "optimizer solve launch");
-	}
-	std::vector<double> hx(static_cast<size_t>(n) * 5), hs(static_cast<size_t>(n) * 8);
-	hipError_t e = hipMemcpyAsync(hx.data(), B.x, hx.size() * 8, hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess)
-	{
-		e = hipMemcpyAsync(hs.data(), B.stats, hs.size() * 8, hipMemcpyDeviceToHost, c->stream);
-	}
-	if (e == hipSuccess)
-	{
-		e = hipStreamSynchronize(c->stream);
-	}
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "D2H optimizer results");
-	}
-	for (int i = 0; i < n; ++i)
-	{
-		for (int k = 0; k < 4; ++k)
-		{
-			poses[4 * i + k] = hx[5 * i + k];
-		}
-		flow_dirs[i] = hx[5 * i + 4];
-		if (summaries)
-		{
-			summaries[i].iterations = static_cast<int32_t>(hs[8 * i + 0]);
-			summaries[i].num_evals_cost = static_cast<int32_t>(hs[8 * i + 1]);
-			summaries[i].num_evals_jac = static_cast<int32_t>(hs[8 * i + 2]);
-			summaries[i].termination = static_cast<int32_t>(hs[8 * i + 3]);
-			summaries[i].initial_cost = hs[8 * i + 4];
-			summaries[i].final_cost = hs[8 * i + 5];
-		}
-	}
-	return EBO_OK;
-}
-
-// ---- packed binary sidecar of an events.txt -------------------------------
-// Parsing the text format costs ~100 ns per event (strtod): at device rates the recording, not
-// the GPU, is the bottleneck.  The sidecar stores what Davis240cReader::getEventSample produces
-// from each line -- the microsecond timestamp AFTER the double -> int64 truncation, x, y, sign --
-// so reading it back gives bit-identical events with no parsing.
-//   header (32 B): magic "EBOEVT1\0", uint64 n_events, uint32 record_bytes (= 16), uint32 flags (0),
-//                  uint64 reserved
-//   record (16 B): int64 t_us, int16 x, int16 y, int8 sign (-1 / +1), 3 bytes 0       little endian
-namespace
-{
-const char kBinMagic[8] = {'E', 'B', 'O', 'E', 'V', 'T', '1', '\0'};
-struct BinHeader
-{
-	char magic[8];
-	uint64_t n;
-	uint32_t record_bytes;
-	uint32_t flags;
-	uint64_t reserved;
-};
-struct BinRecord
-{
-	int64_t t_us;
-	int16_t x, y;
-	int8_t sign;
-	uint8_t pad[3];
-};
-static_assert(sizeof(BinHeader) == 32 && sizeof(BinRecord) == 16, "sidecar layout");
-}  // namespace
-
-int ebo_write_events_bin(const char* path, const ebo_event* ev, size_t n)
-{
-	if (!path || (n && !ev))
-	{
-		return EBO_ERR_ARG;
-	}
-	for (size_t i = 0; i < n; ++i)
-	{
-		if (ev[i].x < -32768 || ev[i].x > 32767 || ev[i].y < -32768 || ev[i].y > 32767 ||
-			(ev[i].sign != 1 && ev[i].sign != -1))
-		{
-			return EBO_ERR_RANGE;
-		}
-	}
-	FILE* fp = std::fopen(path, "wb");
-	if (!fp)
-	{
-		return EBO_ERR_ARG;
-	}
-	BinHeader h;
-	std::memset(&h, 0, sizeof(h));
-	std::memcpy(h.magic, kBinMagic, 8);
-	h.n = n;
-	h.record_bytes = sizeof(BinRecord);
-	bool ok = std::fwrite(&h, sizeof(h), 1, fp) == 1;
-	std::vector<BinRecord> buf(1 << 16);
-	for (size_t i = 0; i < n && ok; i += buf.size())
-	{
-		const size_t m = std::min(buf.size(), n - i);
-		for (size_t k = 0; k < m; ++k)
-		{
-			BinRecord& r = buf[k];
-			r.t_us = ev[i + k].t_us;
-			r.x = static_cast<int16_t>(ev[i + k].x);
-			r.y = static_cast<int16_t>(ev[i + k].y);
-			r.sign = static_cast<int8_t>(ev[i + k].sign);
-			r.pad[0] = r.pad[1] = r.pad[2] = 0;
-		}
-		ok = std::fwrite(buf.data(), sizeof(BinRecord), m, fp) == m;
-	}
-	ok = (std::fclose(fp) == 0) && ok;
-	return ok ? EBO_OK : EBO_ERR_ARG;
-}
-
-int ebo_read_events_bin(const char* path, ebo_event* out, size_t cap, size_t* n)
-{
-	if (!path || !n || (cap && !out))
-	{
-		return EBO_ERR_ARG;
-	}
-	*n = 0;
-	FILE* fp = std::fopen(path, "rb");
-	if (!fp)
-	{
-		return EBO_ERR_ARG;
-	}
-	BinHeader h;
-	if (std::fread(&h, sizeof(h), 1, fp) != 1 || std::memcmp(h.magic, kBinMagic, 8) != 0 ||
-		h.record_bytes != sizeof(BinRecord) || h.flags != 0)
-	{
-		std::fclose(fp);
-		return EBO_ERR_RANGE;
-	}
-	const size_t want = static_cast<size_t>(std::min<uint64_t>(h.n, cap));
-	std::vector<BinRecord> buf(1 << 16);
-	size_t count = 0;
-	int rc = EBO_OK;
-	while (count < want)
-	{
-		const size_t m = std::min(buf.size(), want - count);
-		if (std::fread(buf.data(), sizeof(BinRecord), m, fp) != m)
-		{
-			rc = EBO_ERR_RANGE;  // shorter than its header says
-			break;
-		}
-		for (size_t k = 0; k < m; ++k)
-		{
-			const BinRecord& r = buf[k];
-			if (r.sign != 1 && r.sign != -1)
-			{
-				rc = EBO_ERR_RANGE;
-				break;
-			}
-			ebo_event& e = out[count++];
-			e.x = r.x;
-			e.y = r.y;
-			e.sign = r.sign;
-			e.reserved = 0;
-			e.t_us = r.t_us;
-		}
-		if (rc)
-		{
-			break;
-		}
-	}
-	std::fclose(fp);
-	*n = count;
-	return rc;
-}
-
-// DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one
-// event per line "<seconds> <x> <y> <0|1>".  Seconds go through a double and are
-// truncated to microseconds, exactly as std::stod + duration_cast do there.
-int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
-{
-	if (!path || !n || (cap && !out))
-	{
-		return EBO_ERR_ARG;
-	}
-	*n = 0;
-	FILE* fp = std::fopen(path, "rb");
-	if (!fp)
-	{
-		return EBO_ERR_ARG;
-	}
-	std::vector<char> buf(1 << 20);
-	std::string line;
-	size_t count = 0;
-	int rc = EBO_OK;
-	auto take = [&](const std::string& ln) -> bool {
-		const char* s = ln.c_str();
-		char* end = nullptr;
-		const double sec = std::strtod(s, &end);
-		if (end == s)
-		{
-			return true;  // blank line
-		}
-		const char* p = end;
-		const long x = std::strtol(p, &end, 10);
-		if (end == p)
-		{
-			rc = EBO_ERR_RANGE;
-			return false;
-		}
-		p = end;
-		const long y = std::strtol(p, &end, 10);
-		if (end == p)
-		{
-			rc = EBO_ERR_RANGE;
-			return false;
-		}
-		p = end;
-		const long sign = std::strtol(p, &end, 10);
-		if (end == p || (sign != 0 && sign != 1))
-		{
-			rc = EBO_ERR_RANGE;  // "Sign is not equal to 0/1" (:85-88)
-			return false;
-		}
-		if (count >= cap)
-		{
-			return false;
-		}
-		ebo_event& e = out[count++];
-		e.x = static_cast<int32_t>(x);
-		e.y = static_cast<int32_t>(y);
-		e.sign = sign == 0 ? -1 : 1;
-		e.reserved = 0;
-		e.t_us = static_cast<int64_t>(sec * 1000000.0);
-		return true;
-	};
-	bool go = true;
-	while (go)
-	{
-		const size_t got = std::fread(buf.data(), 1, buf.size(), fp);
-		if (got == 0)
-		{
-			break;
-		}
-		size_t start = 0;
-		for (size_t i = 0; i < got && go; ++i)
-		{
-			if (buf[i] == '\n')
-			{
-				line.append(buf.data() + start, i - start);
-				go = take(line);
-				line.clear();
-				start = i + 1;
-			}
-		}
-		if (go)
-		{
-			line.append(buf.data() + start, got - start);
-		}
-	}
-	if (go && !line.empty())
-	{
-		take(line);
-	}
-	std::fclose(fp);
-	*n = count;
-	return rc;
-}
-
-int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end)
-{
-	if (n_units < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end)
-	{
-		return EBO_ERR_ARG;
-	}
-	const int base = n_units / world, rem = n_units % world;
-	*begin = rank * base + std::min(rank, rem);
-	*end = *begin + base + (rank < rem ? 1 : 0);
-	return EBO_OK;
-}
-
-// ---- RCCL exchange without any framework --------------------------------------
-// librccl.so is loaded lazily with RTLD_LOCAL on the first ebo_comm_* call: a process that
-// brings its own RCCL (PyTorch does) and never calls these entry points is not affected.
-namespace
-{
-struct RcclApi
-{
-	void* handle = nullptr;
-	int (*GetUniqueId)(void*) = nullptr;
-	int (*CommInitRank)(void**, int, ebo_comm_id, int) = nullptr;
-	int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-	int (*CommDestroy)(void*) = nullptr;
-	const char* (*GetErrorString)(int) = nullptr;
-};
-
-RcclApi* rccl_api(std::string& err)
-{
-	static RcclApi api;
-	if (api.handle)
-	{
-		return &api;
-	}
-	const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-	void* h = nullptr;
-	for (const char* n : names)
-	{
-		h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-		if (h)
-		{
-			break;
-		}
-	}
-	if (!h)
-	{
-		err = std::string("cannot load librccl.so: ") + dlerror();
-		return nullptr;
-	}
-	api.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
-	api.CommInitRank = reinterpret_cast<int (*)(void**, int, ebo_comm_id, int)>(dlsym(h, "ncclCommInitRank"));
-	api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
-	api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
-	api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
-	if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy)
-	{
-		err = "librccl.so lacks the expected nccl* symbols";
-		dlclose(h);
-		return nullptr;
-	}
-	api.handle = h;
-	return &api;
-}
-}  // namespace
-
-int ebo_comm_unique_id(ebo_comm_id* id)
-{
-	if (!id)
-	{
-		return EBO_ERR_ARG;
-	}
-	RcclApi* api = rccl_api(g_create_error);
-	if (!api)
-	{
-		return EBO_ERR_COMM;
-	}
-	return api->GetUniqueId(id) == 0 ? EBO_OK : EBO_ERR_COMM;
-}
-
-int ebo_comm_init(ebo_ctx* c, const ebo_comm_id* id, int rank, int nranks)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (!id || nranks <= 0 || rank < 0 || rank >= nranks)
-	{
-		return c->fail(EBO_ERR_ARG, "bad communicator arguments");
-	}
-	RcclApi* api = rccl_api(c->err);
-	if (!api)
-	{
-		return EBO_ERR_COMM;
-	}
-	(void)hipSetDevice(c->prm.device);
-	if (c->comm)
-	{
-		api->CommDestroy(c->comm);
-		c->comm = nullptr;
-	}
-	const int rc = api->CommInitRank(&c->comm, nranks, *id, rank);
-	if (rc != 0)
-	{
-		c->comm = nullptr;
-		return c->fail(EBO_ERR_COMM, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
-	}
-	c->comm_rank = rank;
-	c->comm_size = nranks;
-	return EBO_OK;
-}
-
-int ebo_allgather_device(ebo_ctx* c, const double* d_send, double* d_recv, size_t count_per_rank)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (!c->comm)
-	{
-		return c->fail(EBO_ERR_STATE, "no communicator: call ebo_comm_init first");
-	}
-	if (!d_send || !d_recv)
-	{
-		return c->fail(EBO_ERR_ARG, "null device pointer");
-	}
-	std::string err;
-	RcclApi* api = rccl_api(err);
-	const int rc = api->AllGather(d_send, d_recv, count_per_rank, 8 /* ncclFloat64 */, c->comm, c->stream);
-	if (rc != 0)
-	{
-		return c->fail(EBO_ERR_COMM, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
-	}
-	return EBO_OK;
-}
-
-int ebo_comm_destroy(ebo_ctx* c)
-{
-	if (!c)
-	{
-		return EBO_ERR_ARG;
-	}
-	if (c->comm)
-	{
-		std::string err;
-		RcclApi* api = rccl_api(err);
-		if (api)
-		{
-			(void)hipStreamSynchronize(c->stream);
-			api->CommDestroy(c->comm);
-		}
-		c->comm = nullptr;
-	}
-	return EBO_OK;
 }
 
 int ebo_timer_begin(ebo_ctx* c)

@@ -1,0 +1,230 @@
+// ebo_io.cpp — DAVIS events.txt reader and the packed binary sidecar (include/ebo.h).
+#include "ebo_ctx.h"
+
+using namespace ebo;
+
+extern "C" {
+
+// ---- packed binary sidecar of an events.txt -------------------------------
+// Parsing the text format costs ~100 ns per event (strtod): at device rates the recording, not
+// the GPU, is the bottleneck.  The sidecar stores what Davis240cReader::getEventSample produces
+// from each line -- the microsecond timestamp AFTER the double -> int64 truncation, x, y, sign --
+// so reading it back gives bit-identical events with no parsing.
+//   header (32 B): magic "EBOEVT1\0", uint64 n_events, uint32 record_bytes (= 16), uint32 flags (0),
+//                  uint64 reserved
+//   record (16 B): int64 t_us, int16 x, int16 y, int8 sign (-1 / +1), 3 bytes 0       little endian
+namespace
+{
+const char kBinMagic[8] = {'E', 'B', 'O', 'E', 'V', 'T', '1', '\0'};
+struct BinHeader
+{
+	char magic[8];
+	uint64_t n;
+	uint32_t record_bytes;
+	uint32_t flags;
+	uint64_t reserved;
+};
+struct BinRecord
+{
+	int64_t t_us;
+	int16_t x, y;
+	int8_t sign;
+	uint8_t pad[3];
+};
+static_assert(sizeof(BinHeader) == 32 && sizeof(BinRecord) == 16, "sidecar layout");
+}  // namespace
+
+int ebo_write_events_bin(const char* path, const ebo_event* ev, size_t n)
+{
+	if (!path || (n && !ev))
+	{
+		return EBO_ERR_ARG;
+	}
+	for (size_t i = 0; i < n; ++i)
+	{
+		if (ev[i].x < -32768 || ev[i].x > 32767 || ev[i].y < -32768 || ev[i].y > 32767 ||
+			(ev[i].sign != 1 && ev[i].sign != -1))
+		{
+			return EBO_ERR_RANGE;
+		}
+	}
+	FILE* fp = std::fopen(path, "wb");
+	if (!fp)
+	{
+		return EBO_ERR_ARG;
+	}
+	BinHeader h;
+	std::memset(&h, 0, sizeof(h));
+	std::memcpy(h.magic, kBinMagic, 8);
+	h.n = n;
+	h.record_bytes = sizeof(BinRecord);
+	bool ok = std::fwrite(&h, sizeof(h), 1, fp) == 1;
+	std::vector<BinRecord> buf(1 << 16);
+	for (size_t i = 0; i < n && ok; i += buf.size())
+	{
+		const size_t m = std::min(buf.size(), n - i);
+		for (size_t k = 0; k < m; ++k)
+		{
+			BinRecord& r = buf[k];
+			r.t_us = ev[i + k].t_us;
+			r.x = static_cast<int16_t>(ev[i + k].x);
+			r.y = static_cast<int16_t>(ev[i + k].y);
+			r.sign = static_cast<int8_t>(ev[i + k].sign);
+			r.pad[0] = r.pad[1] = r.pad[2] = 0;
+		}
+		ok = std::fwrite(buf.data(), sizeof(BinRecord), m, fp) == m;
+	}
+	ok = (std::fclose(fp) == 0) && ok;
+	return ok ? EBO_OK : EBO_ERR_ARG;
+}
+
+int ebo_read_events_bin(const char* path, ebo_event* out, size_t cap, size_t* n)
+{
+	if (!path || !n || (cap && !out))
+	{
+		return EBO_ERR_ARG;
+	}
+	*n = 0;
+	FILE* fp = std::fopen(path, "rb");
+	if (!fp)
+	{
+		return EBO_ERR_ARG;
+	}
+	BinHeader h;
+	if (std::fread(&h, sizeof(h), 1, fp) != 1 || std::memcmp(h.magic, kBinMagic, 8) != 0 ||
+		h.record_bytes != sizeof(BinRecord) || h.flags != 0)
+	{
+		std::fclose(fp);
+		return EBO_ERR_RANGE;
+	}
+	const size_t want = static_cast<size_t>(std::min<uint64_t>(h.n, cap));
+	std::vector<BinRecord> buf(1 << 16);
+	size_t count = 0;
+	int rc = EBO_OK;
+	while (count < want)
+	{
+		const size_t m = std::min(buf.size(), want - count);
+		if (std::fread(buf.data(), sizeof(BinRecord), m, fp) != m)
+		{
+			rc = EBO_ERR_RANGE;  // shorter than its header says
+			break;
+		}
+		for (size_t k = 0; k < m; ++k)
+		{
+			const BinRecord& r = buf[k];
+			if (r.sign != 1 && r.sign != -1)
+			{
+				rc = EBO_ERR_RANGE;
+				break;
+			}
+			ebo_event& e = out[count++];
+			e.x = r.x;
+			e.y = r.y;
+			e.sign = r.sign;
+			e.reserved = 0;
+			e.t_us = r.t_us;
+		}
+		if (rc)
+		{
+			break;
+		}
+	}
+	std::fclose(fp);
+	*n = count;
+	return rc;
+}
+
+// DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one
+// event per line "<seconds> <x> <y> <0|1>".  Seconds go through a double and are
+// truncated to microseconds, exactly as std::stod + duration_cast do there.
+int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
+{
+	if (!path || !n || (cap && !out))
+	{
+		return EBO_ERR_ARG;
+	}
+	*n = 0;
+	FILE* fp = std::fopen(path, "rb");
+	if (!fp)
+	{
+		return EBO_ERR_ARG;
+	}
+	std::vector<char> buf(1 << 20);
+	std::string line;
+	size_t count = 0;
+	int rc = EBO_OK;
+	auto take = [&](const std::string& ln) -> bool {
+		const char* s = ln.c_str();
+		char* end = nullptr;
+		const double sec = std::strtod(s, &end);
+		if (end == s)
+		{
+			return true;  // blank line
+		}
+		const char* p = end;
+		const long x = std::strtol(p, &end, 10);
+		if (end == p)
+		{
+			rc = EBO_ERR_RANGE;
+			return false;
+		}
+		p = end;
+		const long y = std::strtol(p, &end, 10);
+		if (end == p)
+		{
+			rc = EBO_ERR_RANGE;
+			return false;
+		}
+		p = end;
+		const long sign = std::strtol(p, &end, 10);
+		if (end == p || (sign != 0 && sign != 1))
+		{
+			rc = EBO_ERR_RANGE;  // "Sign is not equal to 0/1" (:85-88)
+			return false;
+		}
+		if (count >= cap)
+		{
+			return false;
+		}
+		ebo_event& e = out[count++];
+		e.x = static_cast<int32_t>(x);
+		e.y = static_cast<int32_t>(y);
+		e.sign = sign == 0 ? -1 : 1;
+		e.reserved = 0;
+		e.t_us = static_cast<int64_t>(sec * 1000000.0);
+		return true;
+	};
+	bool go = true;
+	while (go)
+	{
+		const size_t got = std::fread(buf.data(), 1, buf.size(), fp);
+		if (got == 0)
+		{
+			break;
+		}
+		size_t start = 0;
+		for (size_t i = 0; i < got && go; ++i)
+		{
+			if (buf[i] == '\n')
+			{
+				line.append(buf.data() + start, i - start);
+				go = take(line);
+				line.clear();
+				start = i + 1;
+			}
+		}
+		if (go)
+		{
+			line.append(buf.data() + start, got - start);
+		}
+	}
+	if (go && !line.empty())
+	{
+		take(line);
+	}
+	std::fclose(fp);
+	*n = count;
+	return rc;
+}
+
+}  // extern "C"
