@@ -1,6 +1,6 @@
 // ebo_ctx.h — private to the host side of libebo_hip.so: the context behind the opaque ebo_ctx
 // of include/ebo.h and the few helpers its translation units share (ebo_api.cpp: context, windows,
-// evaluation, solves, count images; ebo_tracker.cpp: tracked patches; ebo_motion_field.cpp;
+// evaluation, solves, count images; ebo_windows.cpp: loading events; ebo_tracker.cpp: tracked patches; ebo_motion_field.cpp;
 // ebo_io.cpp; ebo_comm.cpp).
 #pragma once
 
