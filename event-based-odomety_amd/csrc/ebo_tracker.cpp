@@ -158,9 +158,9 @@ int ebo_route_set_events(ebo_ctx* c, const ebo_event* ev, size_t n)
 	{
 		return EBO_ERR_ARG;
 	}
-	if ((!ev && n > 0) || n > 0xFFFFFFF0u)
+	if ((!ev && n > 0) || n > 0x7FFFFFFFu)  // k_route's 32-bit indices step by 256: no wrap-around
 	{
-		return c->fail(EBO_ERR_ARG, "null events or more than 2^32 events in a chunk");
+		return c->fail(EBO_ERR_ARG, "null events or more than 2^31 events in a chunk");
 	}
 	(void)hipSetDevice(c->prm.device);
 	c->route_n = 0;
