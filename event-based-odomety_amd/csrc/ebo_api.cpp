@@ -1126,9 +1126,9 @@ int ebo_create(const ebo_params* p, ebo_ctx** out)
 		g_create_error = "unknown loss or gradient mode";
 		return EBO_ERR_ARG;
 	}
-	if (p->max_events >= (1ull << 32))
+	if (p->max_events >= (1ull << 32) - (1ull << 20))  // 32-bit event indices; kernels step in chunks of up to 2^14
 	{
-		g_create_error = "max_events must be below 2^32";
+		g_create_error = "max_events must be below 2^32 - 2^20";
 		return EBO_ERR_ARG;
 	}
 	int cnt = 0;
