@@ -89,8 +89,8 @@ def cpu_baseline_all_cores(cfg_idx, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, help="BASELINE config index (2 = configs[1])")
     ap.add_argument("--windows", type=int, default=256, help="independent windows per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
