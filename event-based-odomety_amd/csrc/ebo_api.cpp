@@ -435,7 +435,7 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 	// Small rounds (a single window's LM round is 108 flows): the kernels read the flows from
 	// and write the results to the pinned buffers themselves; the round is one launch + one
 	// sync.  Larger rounds move the data with async copies (which really are async from pinned).
-	static const size_t zeroCopyMax = env_size("EBO_ZERO_COPY_MAX", 4096);
+	const size_t zeroCopyMax = env_size("EBO_ZERO_COPY_MAX", 4096);
 	const bool zeroCopy = nf <= zeroCopyMax;
 	std::memcpy(c->pin_flows, flows, nf * 2 * sizeof(double));
 	const double* dFlows = c->pin_flows;

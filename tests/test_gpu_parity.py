@@ -421,3 +421,23 @@ def test_error_behaviour(ebo, synth):
         c.set_window(ev)  # still usable after errors
         r, _ = c.eval(np.zeros((c.P, 2)))
         assert r.shape == (1, c.P)
+
+
+def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
+    """Host-driven solves hand flows and results through pinned memory the kernels access directly
+    (small rounds) or through explicit async copies (large ones, EBO_ZERO_COPY_MAX): same bits (variance
+    loss: its evaluation is bit-reproducible; the edge loss's f64 LDS atomics are not)."""
+    ev, offsets, _ = synth.make_stream(0, 3, n_events=6000)
+    out = []
+    for limit in ("4096", "0"):
+        monkeypatch.setenv("EBO_ZERO_COPY_MAX", limit)
+        with ebo.Context(image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_VARIANCE,
+                         max_events=len(ev), max_windows=3) as c:
+            c.set_windows(ev, offsets)
+            opts = ebo.default_solver()
+            opts.max_num_iterations = 6
+            flows, summ = c.solve(opts)
+            r, J = c.eval(flows)
+            out.append((flows.copy(), r.copy(), J.copy(), [s.final_cost for s in summ]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
