@@ -117,8 +117,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    # EBO_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, barrier, reductions) with a
+    # single rank: a rehearsal of that path on a one-GPU box
+    use_dist = world > 1 or os.environ.get("EBO_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
 
@@ -151,7 +155,7 @@ def main():
 
     d_flows = torch.from_numpy(gt * 0.5).to("cuda")  # mid-solve candidate flows
     d_out = torch.zeros((Wn * P, 3), dtype=torch.float64, device="cuda")
-    exchange = world > 1 and args.exchange
+    exchange = use_dist and args.exchange
     d_all = torch.zeros((world * Wn * P, 3), dtype=torch.float64, device="cuda") if exchange else None
 
     def step():
@@ -161,7 +165,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +177,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -403,7 +407,7 @@ def main():
         }
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
