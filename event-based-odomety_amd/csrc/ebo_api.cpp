@@ -358,9 +358,15 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		// Measured (tools/sweep_impl.py): one row band per unit is best at every batch size
 		// (each band workgroup pays the bounding-box pass over all events); with few units
 		// a 512-thread workgroup shortens the per-unit critical path (29 vs 46 us for one
-		// 64-patch window), with many units 256 threads pack the CU better.
+		// 64-patch window); with many units smaller workgroups pack the CU better and waste fewer
+		// lanes in a unit's last round of events: 192 threads against 256, evaluation with
+		// Jacobian at flows 0 / 0.5 / 1.0 x ground truth: C2 +14 / +9 / +7 %, C3 +10 / +8 / +7 %,
+		// C4 +10 / +6 / +6 %, 20x20 patches of 139 events +28 / +25 / +23 % (128 threads: more at
+		// small flows, -12 % at C4 near convergence).  (The sums of a unit are reduced over the
+		// workgroup, so the two regimes differ in the last bits: a window is bit-identical alone
+		// and inside a batch as long as both are on the same side of 1024 units.)
 		const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
-		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : 256));
+		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : 192));
 		if (L.block < 64 || L.block > 512 || (L.block & 63))
 		{
 			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,512]");
@@ -668,7 +674,9 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	{
 		return rc;
 	}
-	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", 256));
+	// 128 threads: 256 windows of C2 solve in 28 ms against 38 ms with 256 threads (192: 39 ms),
+	// 20x20 patches of 139 events in 13 ms against 22 ms
+	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", 128));
 	if (L.block < 64 || L.block > 512 || (L.block & 63))
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_SOLVE_BLOCK must be a multiple of 64 in [64,512]");
