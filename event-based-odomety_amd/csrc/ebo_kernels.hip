@@ -2662,8 +2662,17 @@ int launch_count_image(const CountLaunch& L, void* stream)
 	if ((L.impl == 2 || (L.impl < 0 && L.mode == 0)) && L.d_overflow && L.n_units_total > 0)
 	{
 		const bool u16 = L.max_window_events < 65536;
-		const size_t ldsBytes = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : (L.mode == 0 ? 24 : 76)) * 1024;
 		const size_t rowBytes = static_cast<size_t>(L.c.image_w) * (u16 ? 2 : 4);
+		size_t ldsBytes = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : (L.mode == 0 ? 24 : 76)) * 1024;
+		if (L.lds_kb <= 0 && L.mode == 0)
+		{
+			// un-warped image, measured: ONE patch row per band when it is up to 24 KB of counters
+			// (C2 10.5 KB: 63 -> 67 % of HBM against two rows; C3 22 KB: 71 %), column tiles of
+			// ~16 KB above that (C4: 64 -> 68 % against 24 KB tiles); several rows only when a
+			// patch row is tiny
+			const size_t patchRowBytes = static_cast<size_t>(L.c.patch_h) * rowBytes;
+			ldsBytes = patchRowBytes > 24 * 1024 ? 16 * 1024 : std::max<size_t>(patchRowBytes, 12 * 1024);
+		}
 		const int prb = std::max(1, static_cast<int>(ldsBytes / rowBytes) / L.c.patch_h);
 		const int bandRows = prb * L.c.patch_h;
 		// One patch row already above the target (large sensors; C4: 22 rows x 1280 x 4 B = 112 KB,
