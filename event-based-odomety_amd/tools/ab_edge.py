@@ -28,11 +28,15 @@ for st in sys.argv[3:] or [""]:
     for jac in (1, 0):
         for _ in range(2):
             ctx.eval_device(d_flows.data_ptr(), jac, d_out.data_ptr())
-        torch.cuda.synchronize(); e0.record(stream)
-        for _ in range(5):
-            ctx.eval_device(d_flows.data_ptr(), jac, d_out.data_ptr())
-        e1.record(stream); torch.cuda.synchronize()
-        res.append(e0.elapsed_time(e1) / 5)
+        best = None
+        for _ in range(3):  # best of three batches of 5 launches
+            torch.cuda.synchronize(); e0.record(stream)
+            for _ in range(5):
+                ctx.eval_device(d_flows.data_ptr(), jac, d_out.data_ptr())
+            e1.record(stream); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / 5
+            best = t if best is None else min(best, t)
+        res.append(best)
         if jac:
             out = d_out.cpu().numpy().copy()
     ref = out if ref is None else ref
