@@ -724,6 +724,7 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	L.sort_bins_cap = 0;
 	L.d_sorted = nullptr;
 	L.sorted_cap = 0;
+	L.d_unit_maxdt = c->d_unit_maxdt;
 	if (L.impl < 0 || L.impl == 2 || L.impl == 3)
 	{
 		size_t total = 0;
@@ -1197,6 +1198,7 @@ int ebo_create(const ebo_params* p, ebo_ctx** out)
 	c->own_stream = (e == hipSuccess);
 	if (e == hipSuccess) e = hipMalloc(&c->d_events, c->cap_events * sizeof(uint64_t));
 	if (e == hipSuccess) e = hipMalloc(&c->d_units, static_cast<size_t>(c->cap_windows) * (c->P + 1) * sizeof(Unit));
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_unit_maxdt), static_cast<size_t>(c->cap_windows) * (c->P + 1) * sizeof(int32_t));
 	if (e == hipSuccess) e = hipMalloc(&c->d_flows, nf * 2 * sizeof(double));
 	if (e == hipSuccess) e = hipMalloc(&c->d_out, nf * 3 * sizeof(double));
 	if (e == hipSuccess) e = hipMalloc(&c->d_stats, nf * 4 * sizeof(int32_t));
@@ -1229,6 +1231,7 @@ void ebo_destroy(ebo_ctx* c)
 	(void)ebo_comm_destroy(c);
 	hipFree(c->d_events);
 	hipFree(c->d_units);
+	hipFree(c->d_unit_maxdt);
 	hipFree(c->d_flows);
 	hipFree(c->d_out);
 	if (c->pin_flows)

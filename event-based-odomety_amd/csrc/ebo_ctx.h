@@ -61,6 +61,7 @@ struct ebo_ctx
 
 	uint64_t* d_events = nullptr;
 	Unit* d_units = nullptr;
+	int32_t* d_unit_maxdt = nullptr;  // [units] max |t_ref(window) - t| over the unit's events (count kernels' displacement bound)
 	double* d_flows = nullptr;
 	double* d_out = nullptr;
 	double* d_partials = nullptr;

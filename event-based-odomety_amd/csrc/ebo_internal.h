@@ -170,6 +170,7 @@ struct CountLaunch
 	int sort_bins_cap;               // bins (windows x bands) the buffer holds
 	unsigned int* d_sorted;          // impl 3: [sorted_cap] destination pixels sorted by band, then [sorted_cap] in event order
 	size_t sorted_cap;               // events either half holds
+	const int32_t* d_unit_maxdt;     // [units] max |t_ref(window) - t| per unit (impl 4's displacement bound)
 	uint64_t max_window_events;
 	const void* d_aux;    // flows f64 [Wn][P][2] or field f32 [Wn][H][W][2]
 	int32_t* d_counts;    // [Wn][H][W] scratch, zero on entry, zero on exit
@@ -192,6 +193,7 @@ struct BucketLaunch
 	long long* d_tmax;
 	Unit* d_units;                     // out [n_windows][P+1]
 	long long* d_unit_tref;            // out [n_windows][P+1]
+	int32_t* d_unit_maxdt;             // out [n_windows][P+1]: max |t_ref(window) - t| per unit
 	long long* d_win_tref;             // out [n_windows]
 	uint64_t* d_packed;                // out packed events
 	int* d_flag;                       // out error bits

@@ -1386,6 +1386,160 @@ __global__ void __launch_bounds__(1024) k_count_window_lds(
 	}
 }
 
+// Unit waves (impl 4): workgroup = (row band, window) with the band's counters in LDS, as impl 1;
+// but the events are taken UNIT BY UNIT, one wave per unit at a time (a work counter in LDS hands
+// the units out).  A unit's reference-time offset and flow are then wave-uniform scalars -- no
+// per-event patch lookup, no table reads -- and a band only takes the units whose events can
+// reach it: a unit's rows grown by its largest possible displacement,
+// max|t_ref - t| (kept per unit by the bucketing) x scale x |flow_y|, rounded up.  With several
+// bands a window's events are then warped ~1.2-2 times instead of once per band.
+template <bool U16, int MODE>
+__global__ void __launch_bounds__(1024) k_count_units(
+	const uint64_t* __restrict__ events, const Unit* __restrict__ units, const int32_t* __restrict__ unitMaxDt,
+	int unitsPerWindow, const void* __restrict__ aux, int rowsPerBand, int nWindows, double* __restrict__ image,
+	EvalConsts c)
+{
+	extern __shared__ unsigned int cnt[];
+	const int nBands = (c.image_h + rowsPerBand - 1) / rowsPerBand;
+	const int slot = blockIdx.x >> 3;
+	const int w = (slot / nBands) * 8 + (blockIdx.x & 7);
+	if (w >= nWindows)
+	{
+		return;
+	}
+	const int row0 = (slot % nBands) * rowsPerBand;
+	const int rows = min(rowsPerBand, c.image_h - row0);
+	const int W = c.image_w;
+	const int npx = rows * W;
+	const int nWords = U16 ? (npx + 1) >> 1 : npx;
+	const int P = c.npx * c.npy;
+	const int hdr = (rowsPerBand * W * (U16 ? 2 : 4) + 15) & ~15;  // bytes; the band size of the launch
+	int* ctl = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt) + hdr);  // [0] next, [1] nSel, [2..] list
+	int* list = ctl + 2;
+	for (int i = threadIdx.x; i < nWords; i += blockDim.x)
+	{
+		cnt[i] = 0u;
+	}
+	if (threadIdx.x < 2)
+	{
+		ctl[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
+	const int32_t* wmax = unitMaxDt + static_cast<size_t>(w) * unitsPerWindow;
+	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
+	const double* windowFlows = static_cast<const double*>(aux) + (MODE == 1 ? 2 * static_cast<size_t>(w) * P : 0);
+	const float* windowField = static_cast<const float*>(aux) + (MODE == 2 ? 2 * static_cast<size_t>(w) * imgSize : 0);
+	// which units can reach this band
+	for (int u = threadIdx.x; u <= P; u += blockDim.x)
+	{
+		const Unit un = wu[u];
+		bool take = un.n_ev > 0;
+		if (take && u < P && nBands > 1 && MODE != 2)
+		{
+			double reach = 0.0;
+			if (MODE == 1)
+			{
+				// |fl(fl(dtw * scale) * m1)| <= fl(fl(maxdt * |scale|) * |m1|): rounding is monotonic
+				reach = static_cast<double>(wmax[u]) * fabs(c.scale) * fabs(windowFlows[2 * u + 1]) + 1.0;
+			}
+			const double lo = static_cast<double>(un.ry) - reach, hi = static_cast<double>(un.ry + un.rh - 1) + reach;
+			// NaN / inf reach: comparisons false -> taken
+			take = !(hi < static_cast<double>(row0) - 0.5 || lo > static_cast<double>(row0 + rows) - 0.5);
+		}
+		if (take)
+		{
+			list[atomicAdd(&ctl[1], 1)] = u;
+		}
+	}
+	__syncthreads();
+	const int nSel = ctl[1];
+	const int lane = threadIdx.x & 63;
+	constexpr int kInFlight = 4;
+	for (;;)
+	{
+		int pick = 0;
+		if (lane == 0)
+		{
+			pick = atomicAdd(&ctl[0], 1);
+		}
+		pick = __shfl(pick, 0, 64);
+		if (pick >= nSel)
+		{
+			break;
+		}
+		const int u = list[pick];
+		const Unit un = wu[u];
+		const bool stray = u == P;
+		double m0 = 0.0, m1 = 0.0;
+		if (MODE == 1 && !stray)
+		{
+			m0 = windowFlows[2 * u];
+			m1 = windowFlows[2 * u + 1];
+		}
+		const int dtWin = un.dt_win;
+		const uint32_t evEnd = un.ev_off + un.n_ev;
+		for (uint32_t eb = un.ev_off + lane; eb < evEnd; eb += kInFlight * 64)
+		{
+			uint64_t recs[kInFlight];
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const uint32_t ek = eb + k * 64;
+				recs[k] = (ek < evEnd) ? events[ek] : 0ull;
+			}
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const bool live = eb + k * 64 < evEnd;
+				if (MODE == 1 && stray)
+				{
+					stray_flow(recs[k], windowFlows, c, m0, m1);
+				}
+				int nx, ny;
+				const bool hit = count_target<MODE>(recs[k], live, dtWin, m0, m1, windowField, c, nx, ny);
+				const int ry = ny - row0;
+				if (hit && ry >= 0 && ry < rows)
+				{
+					const int p = ry * W + nx;
+					if (U16)
+					{
+						atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
+					}
+					else
+					{
+						atomicAdd(&cnt[p], 1u);
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W;
+	if (U16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+	{
+		const int pairs = npx >> 1;
+		double2* out2 = reinterpret_cast<double2*>(out);
+		for (int i = threadIdx.x; i < pairs; i += blockDim.x)
+		{
+			const unsigned int v = cnt[i];
+			out2[i] = make_double2(static_cast<double>(v & 0xFFFFu), static_cast<double>(v >> 16));
+		}
+		if ((npx & 1) && threadIdx.x == 0)
+		{
+			out[npx - 1] = static_cast<double>(cnt[pairs] & 0xFFFFu);
+		}
+	}
+	else
+	{
+		for (int p = threadIdx.x; p < npx; p += blockDim.x)
+		{
+			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
+			out[p] = static_cast<double>(v);
+		}
+	}
+}
+
 // Patch-row bands (impl 2): workgroup = (band of whole patch rows, window).  Events are
 // stored unit by unit in patch order, so the events that START in a band are one contiguous
 // range: the workgroup streams only those (no re-reads by other bands, any image size),
@@ -2484,7 +2638,7 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(L.n_windows), dim3(256), 0, s, raw, L.d_offsets,
 					   L.n_windows, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.min_events, L.d_units,
-					   L.d_unit_tref, L.d_win_tref, L.d_flag, L.c);
+					   L.d_unit_tref, L.d_unit_maxdt, L.d_win_tref, L.d_flag, L.c);
 	if (check_launch())
 	{
 		return -2;
@@ -2574,6 +2728,39 @@ int launch_count_image(const CountLaunch& L, void* stream)
 {
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	const size_t n = static_cast<size_t>(L.n_windows) * L.c.image_w * L.c.image_h;
+	// Unit waves (impl 4, k_count_units): the default for images warped by per-patch flows that
+	// need SEVERAL bands, in launches with enough (band, window) workgroups -- C3 x 128 windows
+	// 0.179 -> 0.122 ms against impl 1, C4 x 32 0.311 -> 0.231 ms against impl 3; with one band
+	// (C2) impl 1 is as fast, small launches are better off with global atomics.
+	if ((L.impl == 4 || (L.impl < 0 && L.mode == 1)) && L.d_unit_maxdt && L.n_units_total > 0)
+	{
+		const bool u16 = L.max_window_events < 65536;
+		const int Pn = L.c.npx * L.c.npy;
+		const size_t ctlBytes = static_cast<size_t>(Pn + 3) * 4 + 16;
+		const size_t ldsWant = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 128) * 1024;
+		const size_t ldsBytes = std::min(ldsWant, static_cast<size_t>(160 * 1024 - 1024) - std::min(ctlBytes, static_cast<size_t>(64 * 1024)));
+		const size_t pxPerBand = u16 ? ldsBytes / 2 : ldsBytes / 4;
+		const int rowsPerBand = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
+		if (rowsPerBand > 0 && ctlBytes <= 64 * 1024)
+		{
+			const int bands = (L.c.image_h + rowsPerBand - 1) / rowsPerBand;
+			const bool want4 = L.impl == 4 || (bands > 1 && bands <= 64 && static_cast<long>(L.n_windows) * bands >= 64);
+			auto kern = u16 ? (L.mode == 0	 ? k_count_units<true, 0>
+							   : L.mode == 1 ? k_count_units<true, 1>
+											 : k_count_units<true, 2>)
+							: (L.mode == 0	 ? k_count_units<false, 0>
+							   : L.mode == 1 ? k_count_units<false, 1>
+											 : k_count_units<false, 2>);
+			const size_t lds = ((static_cast<size_t>(rowsPerBand) * L.c.image_w * (u16 ? 2 : 4) + 15) & ~size_t(15)) + ctlBytes;
+			if (want4 && lds <= 160 * 1024 && allow_big_lds(kern, lds) == 0)
+			{
+				const int groups = (L.n_windows + 7) / 8;
+				hipLaunchKernelGGL(kern, dim3(groups * bands * 8), dim3(1024), lds, s, L.d_events, L.d_units, L.d_unit_maxdt,
+								   L.units_per_window, L.d_aux, rowsPerBand, L.n_windows, L.d_image, L.c);
+				return check_launch();
+			}
+		}
+	}
 	// LDS-privatised path when the image splits into few row bands and there are
 	// enough (band, window) workgroups to occupy the chip; else global int atomics.
 	{

@@ -63,6 +63,7 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	L.max_chunks = static_cast<int>((maxWin + 2047) / 2048);
 	L.min_events = c->prm.min_events;
 	L.d_units = c->d_units;
+	L.d_unit_maxdt = c->d_unit_maxdt;
 	L.d_packed = c->d_events;
 	L.c = make_consts(c);
 	// pinned mirror: offsets go up and (units | unit tref, window tref, flag) come back as three
@@ -255,7 +256,8 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 	std::vector<WindowInfo> wins(n_windows);
 	c->h_packed.resize(total);
 	std::vector<uint32_t> cnt(P + 1), cur(P + 1);
-	std::vector<int64_t> first(P + 1), last(P + 1);
+	std::vector<int64_t> first(P + 1), last(P + 1), tlo(P + 1), thi(P + 1);
+	std::vector<int32_t> maxdt(units.size(), 0);
 	size_t base = 0;
 	for (int w = 0; w < n_windows; ++w)
 	{
@@ -293,8 +295,11 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 			if (cnt[b] == 0)
 			{
 				first[b] = we[i].t_us;
+				tlo[b] = thi[b] = we[i].t_us;
 			}
 			last[b] = we[i].t_us;
+			tlo[b] = std::min(tlo[b], we[i].t_us);
+			thi[b] = std::max(thi[b], we[i].t_us);
 			cnt[b]++;
 		}
 		size_t off = base;
@@ -330,6 +335,11 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 				u.flags |= kUnitStray;
 			}
 			utref[static_cast<size_t>(w) * (P + 1) + b] = tu;
+			if (cnt[b] > 0)
+			{
+				const int64_t a = std::llabs(tw - tlo[b]), z = std::llabs(tw - thi[b]);
+				maxdt[static_cast<size_t>(w) * (P + 1) + b] = static_cast<int32_t>(std::min<int64_t>(std::max(a, z), INT32_MAX));
+			}
 			const int64_t dwin = tw - tu;
 			if (dwin < INT32_MIN || dwin > INT32_MAX)
 			{
@@ -378,6 +388,12 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 		rc = c->hip(hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(Unit),
 								   hipMemcpyHostToDevice, c->stream),
 					"H2D units");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipMemcpyAsync(c->d_unit_maxdt, maxdt.data(), maxdt.size() * sizeof(int32_t),
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D unit time spans");
 	}
 	if (rc == EBO_OK)
 	{

@@ -1,6 +1,6 @@
 """GPU tests of the count-image implementations (0: global int atomics, 1: whole-window LDS
 bands, 2: patch-row LDS bands with an overflow list for events that leave their band, 3: events
-sorted by destination band, for the warped images of large sensors): all
+sorted by destination band, 4: unit waves with a displacement bound per unit): all
 bit-exact against the oracle, on single windows and on batches, for all three modes."""
 import numpy as np
 import pytest
@@ -14,7 +14,7 @@ def _prm(orc, c):
                               patch_h=p.patch_h, scale=p.scale, min_events=p.min_events, loss=1)
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "auto"])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "auto"])
 @pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000), (4, 2, 60000)])
 def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config, n_windows, n_events):
     if impl == "auto":
@@ -88,7 +88,7 @@ def test_patch_row_bands_any_band_size_and_large_flows(ebo, orc, synth, monkeypa
             assert np.array_equal(integ[k], orc.integrate_events(sub, 240, 180))
 
 
-@pytest.mark.parametrize("impl", ["1", "3"])
+@pytest.mark.parametrize("impl", ["1", "3", "4"])
 @pytest.mark.parametrize("image,patch", [((16383, 24), (2, 24)), ((16383, 24), (3, 5)), ((16000, 20), (127, 1)),
                                          ((9000, 30), (8999, 7)), ((40, 16383), (1, 16383)), ((64, 48), (1, 1))])
 def test_patch_of_an_event_from_its_coordinates(ebo, orc, monkeypatch, impl, image, patch):
