@@ -2737,13 +2737,19 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		const bool u16 = L.max_window_events < 65536;
 		const int Pn = L.c.npx * L.c.npy;
 		const size_t ctlBytes = static_cast<size_t>(Pn + 3) * 4 + 16;
-		const size_t ldsWant = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 128) * 1024;
+		// 76 KB: two workgroups per CU, so that one's store phase overlaps the other's event phase
+		// (C3: 0.122 -> 0.101 ms against 128 KB bands, C4: 0.228 -> 0.211 ms)
+		const size_t ldsWant = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 76) * 1024;
 		const size_t ldsBytes = std::min(ldsWant, static_cast<size_t>(160 * 1024 - 1024) - std::min(ctlBytes, static_cast<size_t>(64 * 1024)));
 		const size_t pxPerBand = u16 ? ldsBytes / 2 : ldsBytes / 4;
-		const int rowsPerBand = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
-		if (rowsPerBand > 0 && ctlBytes <= 64 * 1024)
+		const int rowsMax = static_cast<int>(std::min<size_t>(pxPerBand / L.c.image_w, L.c.image_h));
+		if (rowsMax > 0 && ctlBytes <= 64 * 1024)
 		{
-			const int bands = (L.c.image_h + rowsPerBand - 1) / rowsPerBand;
+			// bands of EQUAL height (C2: 86 KB of counters are two bands of 90 rows, not 158 + 22:
+			// 0.235 -> 0.176 ms, and better than the single 86 KB band of impl 1, 0.194 ms, which
+			// leaves room for one workgroup per CU only)
+			const int bands = (L.c.image_h + rowsMax - 1) / rowsMax;
+			const int rowsPerBand = (L.c.image_h + bands - 1) / bands;
 			const bool want4 = L.impl == 4 || (bands > 1 && bands <= 64 && static_cast<long>(L.n_windows) * bands >= 64);
 			auto kern = u16 ? (L.mode == 0	 ? k_count_units<true, 0>
 							   : L.mode == 1 ? k_count_units<true, 1>
