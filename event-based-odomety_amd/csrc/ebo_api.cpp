@@ -244,9 +244,25 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	const size_t aliasPerPx = 2 * sizeof(double) + sizeof(int32_t);
 	const char* layoutEnv = std::getenv("EBO_EDGE_LAYOUT");  // 0 / 1 force a layout (A/B)
 	const bool fitsTwice = headerBytes + canvasPx * aliasPerPx + 64 <= 80 * 1024 - 256;
-	L.alias_lds = layoutEnv ? (std::atoi(layoutEnv) != 0) : (fitsTwice ? 1 : 0);
+	// The grid's REGULAR patches decide (the last row / column of a grid absorbs the remainder of
+	// the sensor and can be almost twice as large): when their canvas fits twice, the 20 B layout
+	// runs two workgroups per CU and the few larger border units take the global-memory slice
+	// (C3, 21x16 patches with a 31x20 corner: 1.47 -> 0.95 ms).  And when the 28 B layout cannot
+	// hold the regular canvas in LDS at all but the 20 B one can (C4, 40x22 patches: 120x66 canvas),
+	// the 20 B layout spares most units the global slice (1.92 -> 1.65 ms).
+	const size_t regularPx = c->custom_n ? canvasPx : static_cast<size_t>(9) * c->prm.patch_w * c->prm.patch_h;
+	const bool regularFitsTwice = headerBytes + regularPx * aliasPerPx + 64 <= 80 * 1024 - 256;
+	// (boxes are smaller than the canvas: holding 90 % of it is as good as all of it)
+	const bool onlyAliasFits = headerBytes + regularPx * bytesPerPx + 64 > kLdsBudget &&
+							   headerBytes + (regularPx * 9 / 10) * aliasPerPx + 64 <= kLdsBudget && regularPx <= 8 * 1024;
+	L.alias_lds = layoutEnv ? (std::atoi(layoutEnv) != 0) : ((fitsTwice || regularFitsTwice || onlyAliasFits) ? 1 : 0);
 	const size_t ldsPerPx = L.alias_lds ? aliasPerPx : bytesPerPx;
+	const bool ldsEnv = std::getenv("EBO_EDGE_LDS_KB") != nullptr;
 	size_t ldsBytes = std::min<size_t>(env_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
+	if (L.alias_lds && !layoutEnv && !ldsEnv && !fitsTwice && regularFitsTwice)
+	{
+		ldsBytes = 80 * 1024 - 256;  // two workgroups per CU; larger border units: global slice
+	}
 	// no point in reserving more LDS than the whole canvas needs
 	ldsBytes = std::min(ldsBytes, headerBytes + canvasPx * ldsPerPx + 64);
 	L.cap_px = static_cast<int>((ldsBytes - headerBytes) / ldsPerPx);
