@@ -427,9 +427,10 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 // modes (optional, [n_flows]): 0 = slot not wanted this round (r / jac left as they are),
 // 1 = value only, 2 = value + Jacobian; lets a lock-step solve skip finished problems and
 // Jacobians nobody asked for.
-int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const unsigned char* modes = nullptr)
+// pinned staging of evaluation rounds: flows [nf][2], results [nf][3], and mode tables [4][nf]
+// (the pipelined lock-step solve has up to four rounds in flight)
+int ensure_eval_staging(ebo_ctx* c, size_t nf)
 {
-	const size_t nf = c->n_flows();
 	int rc = EBO_OK;
 	if (nf > c->pin_cap)
 	{
@@ -445,7 +446,7 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 		}
 		hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_flows), nf * 2 * sizeof(double), kZeroCopyFlags);
 		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_out), nf * 3 * sizeof(double), kZeroCopyFlags);
-		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_modes), nf, kZeroCopyFlags);
+		if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pin_modes), 4 * nf, kZeroCopyFlags);  // one table per round in flight (up to 4)
 		rc = c->hip(e, "hipHostMalloc evaluation staging");
 		if (rc)
 		{
@@ -453,6 +454,91 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 		}
 		std::memset(c->pin_out, 0, nf * 3 * sizeof(double));
 		c->pin_cap = nf;
+	}
+	return rc;
+}
+
+int ensure_device_modes(ebo_ctx* c, size_t nf)
+{
+	if (nf > c->modes_cap)
+	{
+		if (c->d_modes)
+		{
+			hipFree(c->d_modes);
+			c->d_modes = nullptr;
+			c->modes_cap = 0;
+		}
+		int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_modes), nf), "hipMalloc modes");
+		if (rc)
+		{
+			return rc;
+		}
+		c->modes_cap = nf;
+	}
+	return EBO_OK;
+}
+
+// One half of a pipelined lock-step round: slots [s0, s1) of the flows go up, the launch covers
+// every unit with the mode table `modes` (zero outside the half: those workgroups exit at once),
+// the half's results come back, and `done` marks the end; nothing here waits.
+int eval_begin(ebo_ctx* c, const double* flows, const unsigned char* modes, int which, size_t s0, size_t s1, bool wantJac,
+			   hipEvent_t done)
+{
+	const size_t nf = c->n_flows();
+	std::memcpy(c->pin_flows + 2 * s0, flows + 2 * s0, (s1 - s0) * 2 * sizeof(double));
+	hipError_t e = hipMemcpyAsync(c->d_flows + 2 * s0, c->pin_flows + 2 * s0, (s1 - s0) * 2 * sizeof(double),
+								  hipMemcpyHostToDevice, c->stream);
+	unsigned char* pm = c->pin_modes + static_cast<size_t>(which) * nf;
+	std::memcpy(pm, modes, nf);
+	if (e == hipSuccess) e = hipMemcpyAsync(c->d_modes, pm, nf, hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D round");
+	}
+	c->modes_active = c->d_modes;
+	int rc = run_eval_device(c, c->d_flows, wantJac, c->d_out);
+	c->modes_active = nullptr;
+	if (rc)
+	{
+		return rc;
+	}
+	e = hipMemcpyAsync(c->pin_out + 3 * s0, c->d_out + 3 * s0, (s1 - s0) * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipEventRecord(done, c->stream);
+	return c->hip(e, "D2H round");
+}
+
+int eval_finish(ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, bool wantJac, double* r, double* jac,
+				hipEvent_t done)
+{
+	int rc = c->hip(hipEventSynchronize(done), "round");
+	if (rc)
+	{
+		return rc;
+	}
+	const double* h_out = c->pin_out;
+	for (size_t i = s0; i < s1; ++i)
+	{
+		if (modes[i] == 0)
+		{
+			continue;
+		}
+		r[i] = h_out[3 * i];
+		if (wantJac && modes[i] == 2)
+		{
+			jac[2 * i] = h_out[3 * i + 1];
+			jac[2 * i + 1] = h_out[3 * i + 2];
+		}
+	}
+	return EBO_OK;
+}
+
+int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const unsigned char* modes = nullptr)
+{
+	const size_t nf = c->n_flows();
+	int rc = ensure_eval_staging(c, nf);
+	if (rc)
+	{
+		return rc;
 	}
 	// Small rounds (a single window's LM round is 108 flows): the kernels read the flows from
 	// and write the results to the pinned buffers themselves; the round is one launch + one
@@ -479,20 +565,10 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 		c->modes_active = c->pin_modes;
 		if (!zeroCopy)
 		{
-			if (nf > c->modes_cap)
+			rc = ensure_device_modes(c, nf);
+			if (rc)
 			{
-				if (c->d_modes)
-				{
-					hipFree(c->d_modes);
-					c->d_modes = nullptr;
-					c->modes_cap = 0;
-				}
-				rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_modes), nf), "hipMalloc modes");
-				if (rc)
-				{
-					return rc;
-				}
-				c->modes_cap = nf;
+				return rc;
 			}
 			rc = c->hip(hipMemcpyAsync(c->d_modes, c->pin_modes, nf, hipMemcpyHostToDevice, c->stream), "H2D modes");
 			if (rc)
@@ -839,8 +915,132 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
 	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
 	HostPool pool(static_cast<size_t>(Wn), 8);
+	// EBO_SOLVE_TRACE=1: where a lock-step solve spends its time (stderr, one line per call)
+	const bool trace = std::getenv("EBO_SOLVE_TRACE") != nullptr;
+	double tReq = 0.0, tEval = 0.0, tSup = 0.0;
+	int rounds = 0;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return std::chrono::duration<double, std::milli>(b - a).count();
+	};
+	// Many windows: two halves in flight.  While the device evaluates one half, the host takes the
+	// other half's results, runs its LM steps and asks for its next points -- with 256 windows of
+	// the reference configuration the host side (16 ms of LM steps and requests per solve) had
+	// grown to half of the wall time once the kernels got faster.  Per window the sequence of
+	// requests and evaluations is unchanged: same results.
+	const size_t nfAll = static_cast<size_t>(Wn) * P;
+	if (Wn >= 16 && nfAll > env_size("EBO_ZERO_COPY_MAX", 4096) && !std::getenv("EBO_SOLVE_NO_PIPELINE"))
+	{
+		int rc = ensure_eval_staging(c, nfAll);
+		if (rc == EBO_OK) rc = ensure_device_modes(c, nfAll);
+		if (rc)
+		{
+			return rc;
+		}
+		constexpr int kMaxGroups = 4;
+		const int G = static_cast<int>(std::min<size_t>(std::max<size_t>(env_size("EBO_SOLVE_GROUPS", 2), 2), kMaxGroups));
+		hipEvent_t done[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+		for (int g = 0; g < G; ++g)
+		{
+			if (hipEventCreateWithFlags(&done[g], hipEventDisableTiming) != hipSuccess)
+			{
+				for (int k = 0; k < g; ++k) (void)hipEventDestroy(done[k]);
+				return c->fail(EBO_ERR_HIP, "hipEventCreate");
+			}
+		}
+		size_t wSplit[kMaxGroups + 1];
+		for (int g = 0; g <= G; ++g)
+		{
+			wSplit[g] = static_cast<size_t>(Wn) * g / G;
+		}
+		std::vector<unsigned char> gmodes[kMaxGroups];
+		for (int g = 0; g < G; ++g)
+		{
+			gmodes[g].assign(nfAll, 0);
+		}
+		bool inflight[kMaxGroups] = {false, false, false, false}, gJac[kMaxGroups] = {false, false, false, false};
+		// request: every window of the half says what it wants next; true if any is still running
+		auto request = [&](int g) {
+			pool.parallel_for(wSplit[g + 1] - wSplit[g], 8, [&](size_t b, size_t e) {
+				for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
+				{
+					const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
+					wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+					std::memset(&gmodes[g][w * P], wmode[w], static_cast<size_t>(P));
+				}
+			});
+			bool any = false;
+			gJac[g] = false;
+			for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
+			{
+				any = any || wmode[w] != 0;
+				gJac[g] = gJac[g] || wmode[w] == 2;
+			}
+			return any;
+		};
+		auto launch = [&](int g) {
+			inflight[g] = true;
+			++rounds;
+			return eval_begin(c, flows.data(), gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g], done[g]);
+		};
+		for (int g = 0; g < G && rc == EBO_OK; ++g)
+		{
+			if (request(g))
+			{
+				rc = launch(g);
+			}
+		}
+		auto anyInflight = [&] { for (int g = 0; g < G; ++g) { if (inflight[g]) return true; } return false; };
+		while (rc == EBO_OK && anyInflight())
+		{
+			for (int g = 0; g < G && rc == EBO_OK; ++g)
+			{
+				if (!inflight[g])
+				{
+					continue;
+				}
+				const auto t1 = now();
+				rc = eval_finish(c, gmodes[g].data(), wSplit[g] * P, wSplit[g + 1] * P, gJac[g], r.data(), J.data(), done[g]);
+				inflight[g] = false;
+				if (rc)
+				{
+					break;
+				}
+				const auto t2 = now();
+				pool.parallel_for(wSplit[g + 1] - wSplit[g], 8, [&](size_t b, size_t e) {
+					for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
+					{
+						if (wmode[w] != 0)
+						{
+							lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
+						}
+					}
+				});
+				const auto t3 = now();
+				const bool more = request(g);
+				tEval += ms(t1, t2);
+				tSup += ms(t2, t3);
+				tReq += ms(t3, now());
+				if (more)
+				{
+					rc = launch(g);
+				}
+			}
+		}
+		(void)hipStreamSynchronize(c->stream);
+		for (int g = 0; g < G; ++g)
+		{
+			(void)hipEventDestroy(done[g]);
+		}
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	else
 	for (;;)
 	{
+		const auto t0 = now();
 		// every window says what it wants next (its own point, value or value + Jacobian);
 		// finished windows drop out of the launch
 		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
@@ -863,11 +1063,13 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 			break;
 		}
 		// all windows in the same phase (always so for a single window): no mode table needed
+		const auto t1 = now();
 		int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr, uniform ? nullptr : modes.data());
 		if (rc)
 		{
 			return rc;
 		}
+		const auto t2 = now();
 		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
 			for (size_t w = b; w < e; ++w)
 			{
@@ -877,6 +1079,16 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 				}
 			}
 		});
+		const auto t3 = now();
+		tReq += ms(t0, t1);
+		tEval += ms(t1, t2);
+		tSup += ms(t2, t3);
+		++rounds;
+	}
+	if (trace)
+	{
+		std::fprintf(stderr, "[ebo] lock-step solve: %d windows, %d rounds: request %.2f ms, evaluation (staging + kernels + sync; pipelined: waiting only) %.2f ms, supply (LM steps) %.2f ms\n",
+					 Wn, rounds, tReq, tEval, tSup);
 	}
 	int worst = 0;
 	for (int w = 0; w < Wn; ++w)

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>

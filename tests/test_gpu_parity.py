@@ -441,3 +441,35 @@ def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
             out.append((flows.copy(), r.copy(), J.copy(), [s.final_cost for s in summ]))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+
+
+def test_pipelined_lock_step_solve_equals_the_plain_one(ebo, synth, monkeypatch):
+    """With 16 or more windows the TV-coupled host LM runs two halves in flight (one half's LM steps
+    on the host while the device evaluates the other): per window the same requests in the same
+    order, so the same bits as the one-round-at-a-time loop; and the same answer as a window alone."""
+    n = 21
+    ev, offsets, _ = synth.make_stream(0, n, n_events=5000)
+    kw = dict(image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_VARIANCE, max_events=len(ev), max_windows=n)
+    out = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("EBO_SOLVE_NO_PIPELINE", "1")
+        else:
+            monkeypatch.delenv("EBO_SOLVE_NO_PIPELINE", raising=False)
+        with ebo.Context(**kw) as c:
+            c.set_windows(ev, offsets)
+            opts = ebo.default_solver()
+            opts.max_num_iterations = 12
+            flows, summ = c.solve(opts)
+            out.append((flows.copy(), [(s.iterations, s.final_cost, s.termination) for s in summ]))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    monkeypatch.delenv("EBO_SOLVE_NO_PIPELINE", raising=False)
+    for w in (0, 10, 20):
+        sub = ev[int(offsets[w]):int(offsets[w + 1])]
+        with ebo.Context(**dict(kw, max_events=len(sub), max_windows=1)) as c:
+            c.set_window(sub)
+            opts = ebo.default_solver()
+            opts.max_num_iterations = 12
+            alone, s1 = c.solve(opts)
+        np.testing.assert_allclose(alone[0], out[0][0][w], rtol=0, atol=1e-7)
+        assert s1[0].iterations == out[0][1][w][0]
