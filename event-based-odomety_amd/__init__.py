@@ -21,8 +21,8 @@ LIB_PATH = os.path.join(HERE, "libebo_hip.so")
 HEADER_PATH = os.path.join(ROOT, "include", "ebo.h")
 
 OK = 0
-ERR_ARG, ERR_HIP, ERR_RANGE, ERR_STATE, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SOLVER = (
-    -1, -2, -3, -4, -5, -6, -7)
+ERR_ARG, ERR_HIP, ERR_RANGE, ERR_STATE, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SOLVER, ERR_COMM = (
+    -1, -2, -3, -4, -5, -6, -7, -8)
 LOSS_EDGE, LOSS_VARIANCE = 0, 1
 GRAD_JET, GRAD_CENTRAL = 0, 1
 SOLVE_GLOBAL, SOLVE_INDEPENDENT = 0, 1
@@ -32,6 +32,9 @@ COUNT_INTEGRATED, COUNT_WARPED, COUNT_FIELD = 0, 1, 2
 EVENT_DTYPE = np.dtype(
     [("x", "<i4"), ("y", "<i4"), ("sign", "<i4"), ("reserved", "<i4"), ("t_us", "<i8")]
 )
+
+# numpy mirror of ebo_track_point (one "feature_id timestamp x y" record, 32 bytes)
+TRACK_DTYPE = np.dtype([("id", "<i8"), ("t_us", "<i8"), ("x", "<f8"), ("y", "<f8")])
 
 
 class FunctorConsts(C.Structure):
@@ -223,6 +226,23 @@ def read_events_bin(path, cap=1 << 24):
     rc = lib().ebo_read_events_bin(str(path).encode(), _vp(out), C.c_size_t(cap), C.byref(n))
     if rc:
         raise EboError(rc, "cannot read %s (read %d events before the error)" % (path, n.value))
+    return out[: n.value].copy()
+
+
+def write_tracks_txt(path, pts):
+    """trajectory.txt as tools::Evaluator::saveFeaturesTrajectory writes it (evaluator.cpp:125-150)."""
+    pts = np.ascontiguousarray(pts, dtype=TRACK_DTYPE)
+    rc = lib().ebo_write_tracks_txt(str(path).encode(), _vp(pts), C.c_size_t(len(pts)))
+    if rc:
+        raise EboError(rc, "cannot write %s" % path)
+
+
+def read_tracks_txt(path, cap=1 << 20):
+    out = np.zeros(cap, dtype=TRACK_DTYPE)
+    n = C.c_size_t()
+    rc = lib().ebo_read_tracks_txt(str(path).encode(), _vp(out), C.c_size_t(cap), C.byref(n))
+    if rc:
+        raise EboError(rc, "cannot parse %s (parsed %d records before the error)" % (path, n.value))
     return out[: n.value].copy()
 
 
@@ -526,10 +546,26 @@ class Context:
     def comm_init(self, comm_id, rank, nranks):
         buf = (C.c_char * 128).from_buffer_copy(bytes(comm_id))
         self._check(lib().ebo_comm_init(self._h, C.byref(buf), int(rank), int(nranks)))
+        self._nranks = int(nranks)
 
     def allgather_device(self, d_send, d_recv, count_per_rank):
         self._check(lib().ebo_allgather_device(
             self._h, C.c_void_p(int(d_send)), C.c_void_p(int(d_recv)), C.c_size_t(int(count_per_rank))))
+
+    def allgather_tracks(self, local):
+        """Every rank's track records on every rank (rank order): -> (records, counts per rank)."""
+        local = np.ascontiguousarray(local, dtype=TRACK_DTYPE)
+        nr = C.c_size_t()
+        counts = np.zeros(max(getattr(self, "_nranks", 1), 1), dtype=np.uint64)
+        rc = lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), None, C.c_size_t(0),
+                                        C.byref(nr), _vp(counts))
+        if rc and not (rc == ERR_ARG and nr.value > 0):
+            self._check(rc)
+        out = np.zeros(nr.value, dtype=TRACK_DTYPE)
+        if nr.value:
+            self._check(lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), _vp(out),
+                                                   C.c_size_t(len(out)), C.byref(nr), _vp(counts)))
+        return out, counts.astype(np.int64)
 
     def comm_destroy(self):
         self._check(lib().ebo_comm_destroy(self._h))

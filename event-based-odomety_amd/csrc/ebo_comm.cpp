@@ -140,6 +140,114 @@ int ebo_allgather_device(ebo_ctx* c, const double* d_send, double* d_recv, size_
 	return EBO_OK;
 }
 
+// Config 5's exchange: variable-length per-rank lists of 32-byte track records.
+// Layout of the context's scratch: [send: maxN records][recv: nranks x maxN records]; the
+// counts travel first through the head of the same buffer.
+int ebo_allgather_tracks(ebo_ctx* c, const ebo_track_point* local, size_t n_local, ebo_track_point* all,
+						 size_t cap, size_t* n_all, size_t* counts)
+{
+	static_assert(sizeof(ebo_track_point) == 32, "track record layout");
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!c->comm)
+	{
+		return c->fail(EBO_ERR_STATE, "no communicator: call ebo_comm_init first");
+	}
+	if ((n_local && !local) || !n_all || (cap && !all))
+	{
+		return c->fail(EBO_ERR_ARG, "null pointer");
+	}
+	std::string err;
+	RcclApi* api = rccl_api(err);
+	(void)hipSetDevice(c->prm.device);
+	const size_t nr = static_cast<size_t>(c->comm_size);
+	int rc = ensure_scratch(c, (nr + 1) * sizeof(uint64_t));
+	if (rc)
+	{
+		return rc;
+	}
+	// 1. counts
+	uint64_t* d_cnt = static_cast<uint64_t*>(c->d_scratch);
+	const uint64_t mine = n_local;
+	std::vector<uint64_t> cnt(nr, 0);
+	hipError_t e = hipMemcpyAsync(d_cnt, &mine, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D track count");
+	}
+	int nrc = api->AllGather(d_cnt, d_cnt + 1, 1, 5 /* ncclUint64 */, c->comm, c->stream);
+	if (nrc != 0)
+	{
+		return c->fail(EBO_ERR_COMM, std::string("ncclAllGather(counts): ") + (api->GetErrorString ? api->GetErrorString(nrc) : "error"));
+	}
+	e = hipMemcpyAsync(cnt.data(), d_cnt + 1, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "track counts");
+	}
+	size_t total = 0, maxN = 0;
+	for (size_t q = 0; q < nr; ++q)
+	{
+		total += cnt[q];
+		maxN = std::max<size_t>(maxN, cnt[q]);
+		if (counts)
+		{
+			counts[q] = cnt[q];
+		}
+	}
+	*n_all = total;
+	if (cnt[static_cast<size_t>(c->comm_rank)] != n_local)
+	{
+		return c->fail(EBO_ERR_COMM, "track count of this rank came back changed");
+	}
+	if (total > cap)
+	{
+		return c->fail(EBO_ERR_ARG, "track output buffer too small");
+	}
+	if (maxN == 0)
+	{
+		return EBO_OK;
+	}
+	// 2. one all-gather of max-padded records
+	const size_t slot = maxN * sizeof(ebo_track_point);
+	rc = ensure_scratch(c, (nr + 1) * slot);
+	if (rc)
+	{
+		return rc;
+	}
+	char* d_send = static_cast<char*>(c->d_scratch);
+	char* d_recv = d_send + slot;
+	e = hipMemsetAsync(d_send, 0, slot, c->stream);
+	if (e == hipSuccess && n_local)
+	{
+		e = hipMemcpyAsync(d_send, local, n_local * sizeof(ebo_track_point), hipMemcpyHostToDevice, c->stream);
+	}
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D tracks");
+	}
+	nrc = api->AllGather(d_send, d_recv, slot, 0 /* ncclInt8 */, c->comm, c->stream);
+	if (nrc != 0)
+	{
+		return c->fail(EBO_ERR_COMM, std::string("ncclAllGather(tracks): ") + (api->GetErrorString ? api->GetErrorString(nrc) : "error"));
+	}
+	// compacting copies: rank q's real records only
+	size_t at = 0;
+	for (size_t q = 0; q < nr && e == hipSuccess; ++q)
+	{
+		if (cnt[q])
+		{
+			e = hipMemcpyAsync(all + at, d_recv + q * slot, cnt[q] * sizeof(ebo_track_point), hipMemcpyDeviceToHost, c->stream);
+			at += cnt[q];
+		}
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	return c->hip(e, "D2H tracks");
+}
+
 int ebo_comm_destroy(ebo_ctx* c)
 {
 	if (!c)

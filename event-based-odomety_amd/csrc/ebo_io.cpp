@@ -227,4 +227,90 @@ int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
 	return rc;
 }
 
+// trajectory.txt of tools::Evaluator::saveFeaturesTrajectory (tools/evaluator/src/evaluator.cpp:125-150):
+// `trajFile << std::fixed << std::setprecision(8) << id << " " << duration<double>(ts).count()
+//  << " " << x << " " << y << std::endl` per trajectory point, patch by patch.  duration<double>
+// of microseconds is count / 1e6 (one division); "%.8f" is what std::fixed + setprecision(8) prints.
+int ebo_write_tracks_txt(const char* path, const ebo_track_point* pts, size_t n)
+{
+	if (!path || (n && !pts))
+	{
+		return EBO_ERR_ARG;
+	}
+	FILE* fp = std::fopen(path, "wb");
+	if (!fp)
+	{
+		return EBO_ERR_ARG;
+	}
+	bool ok = true;
+	for (size_t i = 0; i < n && ok; ++i)
+	{
+		const double sec = static_cast<double>(pts[i].t_us) / 1000000.0;
+		ok = std::fprintf(fp, "%lld %.8f %.8f %.8f\n", static_cast<long long>(pts[i].id), sec, pts[i].x, pts[i].y) > 0;
+	}
+	ok = (std::fclose(fp) == 0) && ok;
+	return ok ? EBO_OK : EBO_ERR_ARG;
+}
+
+int ebo_read_tracks_txt(const char* path, ebo_track_point* out, size_t cap, size_t* n)
+{
+	if (!path || !n || (cap && !out))
+	{
+		return EBO_ERR_ARG;
+	}
+	*n = 0;
+	FILE* fp = std::fopen(path, "rb");
+	if (!fp)
+	{
+		return EBO_ERR_ARG;
+	}
+	char line[512];
+	size_t count = 0;
+	int rc = EBO_OK;
+	while (count < cap && std::fgets(line, sizeof(line), fp))
+	{
+		char* end = nullptr;
+		const long long id = std::strtoll(line, &end, 10);
+		if (end == line)
+		{
+			const char* s = line;
+			while (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\n')
+			{
+				++s;
+			}
+			if (*s == '\0')
+			{
+				continue;  // blank line
+			}
+			rc = EBO_ERR_RANGE;
+			break;
+		}
+		double v[3];
+		bool bad = false;
+		for (int k = 0; k < 3; ++k)
+		{
+			const char* p = end;
+			v[k] = std::strtod(p, &end);
+			if (end == p)
+			{
+				bad = true;
+				break;
+			}
+		}
+		if (bad)
+		{
+			rc = EBO_ERR_RANGE;
+			break;
+		}
+		ebo_track_point& t = out[count++];
+		t.id = id;
+		t.t_us = static_cast<int64_t>(std::llround(v[0] * 1000000.0));
+		t.x = v[1];
+		t.y = v[2];
+	}
+	std::fclose(fp);
+	*n = count;
+	return rc;
+}
+
 }  // extern "C"

@@ -334,6 +334,34 @@ int ebo_comm_init(ebo_ctx* ctx, const ebo_comm_id* id, int rank, int nranks);
 int ebo_allgather_device(ebo_ctx* ctx, const double* d_send, double* d_recv, size_t count_per_rank);
 int ebo_comm_destroy(ebo_ctx* ctx);
 
+/* One sample of a tracked feature's trajectory, the record tools::Evaluator::saveFeaturesTrajectory
+ * writes as "feature_id timestamp x y" (tools/evaluator/src/evaluator.cpp:125-150): Patch::getTrackId()
+ * and one common::Sample<Point2d> of Patch::getTrajectory(). */
+typedef struct ebo_track_point
+{
+	int64_t id;   /* Patch::getTrackId()                 */
+	int64_t t_us; /* pos.timestamp (microseconds)        */
+	double x, y;  /* pos.value                           */
+} ebo_track_point;
+
+/* The exchange of BASELINE config 5 (independent sequences, one per GPU): every rank
+ * contributes the n_local track points of ITS sequence (host memory, any count, 0 allowed) and
+ * every rank receives all of them, rank 0's first, each rank's in the order given.  Two
+ * collectives on the context's stream: an all-gather of the counts, then ONE ncclAllGather of
+ * max-count-padded 32-byte records; the padding is dropped on the way back to the host.
+ * all [cap] (host) receives *n_all records; counts [nranks] (may be NULL) the per-rank counts.
+ * EBO_ERR_STATE without ebo_comm_init; EBO_ERR_ARG when cap is too small (*n_all and counts are
+ * still set, nothing is written to all).  Synchronous. */
+int ebo_allgather_tracks(ebo_ctx* ctx, const ebo_track_point* local, size_t n_local, ebo_track_point* all,
+						 size_t cap, size_t* n_all, size_t* counts);
+
+/* trajectory.txt as saveFeaturesTrajectory writes it (evaluator.cpp:125-150): one line
+ * "<id> <seconds> <x> <y>" per point, std::fixed with 8 decimals, seconds =
+ * std::chrono::duration<double>(timestamp).  Host only.  ebo_read_tracks_txt parses that format
+ * back (seconds -> microseconds rounded to nearest); EBO_ERR_RANGE on a malformed line. */
+int ebo_write_tracks_txt(const char* path, const ebo_track_point* pts, size_t n);
+int ebo_read_tracks_txt(const char* path, ebo_track_point* out, size_t cap, size_t* n);
+
 /* Device-side timing of everything enqueued between begin and end on the
  * context's stream (hipEvent based). */
 int ebo_timer_begin(ebo_ctx* ctx);

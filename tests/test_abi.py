@@ -39,6 +39,7 @@ def test_library_has_gfx950_code_object(ebo):
 
 def test_struct_layouts_match_header(ebo, orc):
     assert ebo.EVENT_DTYPE.itemsize == 24 and orc.EVENT_DTYPE == ebo.EVENT_DTYPE
+    assert ebo.TRACK_DTYPE.itemsize == 32  # ebo_track_point {int64 id, int64 t_us, double x, y}
     p = ebo.default_params()
     assert (p.image_w, p.image_h, p.patch_w, p.patch_h) == (240, 180, 20, 20)  # feature_detector.h:17,25
     assert (p.tv_weight, p.tv_huber, p.scale, p.min_events) == (1e3, 10.0, 1e-3, 100)  # :26-29
