@@ -1,20 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — Mevents/s warped+scored on MI355X (BASELINE.json's metric).
+"""bench.py — Mevents/s warped+scored on MI355X (BASELINE.json's metric), at every N.
 
-A step = ONE batched objective evaluation (value + Jacobian of the variance-contrast
-objective, EBO_GRAD_JET) of every patch of `--windows` independent windows of the
-BASELINE config (default configs[1]: 240x180, 64 patches, 50k events/window), i.e.
-every event is warped by its patch's candidate flow, splatted and scored once per
-step.  Events, patch table and flows are resident in HBM before the timed region.
-Windows are independent problems (the reference re-initialises the flow to 0 for each
-window, feature_detector.cpp:318-326), so a stream is evaluated many windows at a time.
+    python bench.py --gpus N --steps K --warmup W
 
-N > 1 (torchrun, one rank per GPU): the windows (units) are sharded over ranks and each
-rank evaluates its own shard.  Whole windows are independent problems, so the data path
-has NO collective; RCCL carries only the barrier and the max-over-ranks of the timing.
-(`--exchange` adds the one exchange the path has when a SINGLE window is sharded over
-GPUs — C4's 128 patches per GPU: an all-gather of the (r, J0, J1) triples per step for the
-replicated host solver)  Per-GPU work is fixed as N grows => weak scaling.
+One event-evaluation = one event warped by its patch's candidate flow, splatted and scored once
+(SURVEY §8(d)).  Inputs (packed events, unit tables, flows) are resident in HBM before the timed
+region.  Three workloads; `--workload auto` (default) picks by N:
+
+  eval      N = 1 default.  A step = ONE batched value+Jacobian evaluation of the variance-contrast
+            objective (EBO_GRAD_JET) over `--windows` independent windows of BASELINE configs[2]
+            (C3: 346x260, 256 patches, 200 k events/window — the largest single-GPU configuration).
+            With N > 1 every rank evaluates its own windows, no data-path collective.
+  c4        N > 1 default = BASELINE configs[3]: 1280x720 windows of 1024 patches / 1 M events whose
+            PATCH ROWS are sharded over the N GPUs (ebo_shard_range + ebo_set_patches: 32 grid
+            rows -> 32/N rows = 1024/N patches per window per GPU).  A step = the device-resident
+            per-patch solve of the rank's shard (ebo_solve_device, one launch) + ONE RCCL all-gather of
+            the solved flows (16 B per patch), after which every rank holds every window's flows.
+            `--c4-windows` windows PER GPU are in flight (N x that many windows in the batch), so
+            the per-GPU work is fixed as N grows: weak scaling.  value = event-evaluations of the
+            solves (events x objective evaluations, from the solver's own statistics) per second.
+  replicas  BASELINE configs[4]: N independent 346x260 sequences, one per GPU.  A step = the rank's
+            batched evaluation (as `eval`) + one solve of the rank's tracked feature patches
+            (ebo_optimizer_solve) whose new trajectory points join the rank's tracks + ONE gather of
+            all ranks' variable-length (id, t, x, y) track lists (counts + max-padded all-gather).
+
+N > 1 without a launcher: `python bench.py --gpus N` spawns `python -m torch.distributed.run
+--nproc-per-node N` on itself BEFORE anything touches the GPU and relays the children's output;
+under torchrun (WORLD_SIZE set) it just runs as rank RANK.  EBO_BENCH_REHEARSE=1 rehearses the
+N > 1 code path on a box with fewer GPUs than ranks (all ranks share the visible GPUs, collectives
+over gloo) and says so in the JSON line — never a scaling measurement.
 
 Prints ONE JSON line on rank 0.
 """
@@ -22,6 +36,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,9 +52,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_EVENT_EVAL = 8  # packed {x:15, pol:1, y:15, dt:32}; SURVEY §8(d)
 
 
+# --------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (CPU restatement of the reference path; the reference itself cannot be
+# built in this image) timed on this box's host cores, single thread like the reference (F1).
+# --------------------------------------------------------------------------------------------
 def cpu_baseline(synth, cfg_idx, seconds_budget):
-    """The oracle (CPU port of the reference path, single thread like the reference)
-    timed on this box's host cores on a bounded sample of the same workload."""
     import orc
     cfg = synth.CONFIGS[cfg_idx]
     ev, gt = synth.make_window(cfg_idx)
@@ -48,17 +66,62 @@ def cpu_baseline(synth, cfg_idx, seconds_budget):
     sec, n = orc.window_eval_timed(ev, prm, flows, True, 1)  # warm-up + calibration
     reps = max(1, min(2000, int(seconds_budget / max(sec, 1e-6))))
     sec, n = orc.window_eval_timed(ev, prm, flows, True, reps)
-    return {
+    base = {
         "value": n / sec / 1e6, "unit": "Mevents/s", "cores": 1, "kind": "port",
         "sample": "%d value+Jacobian evaluations of 1 window of %s (%d event-evaluations, %.1f s) "
                   "by oracle/liboracle.so, single thread like the reference" % (reps, cfg["name"], n, sec),
     }
+    legs = {}
+    # (ii) a full per-patch solve of one window (the reference-default configuration: 15 k events,
+    # 108 patches of 20x20, the solve the `c4` workload runs per shard), event-evaluations/s
+    try:
+        ev0, _ = synth.make_window(0)
+        prm0 = orc.default_params(loss=1, tv_weight=0.0)
+        opts = orc.default_solver(mode=1)
+        t0 = time.perf_counter()
+        _, _, summ = orc.compensate_events_contrast(ev0, prm0, opts, want_image=False)
+        dt = time.perf_counter() - t0
+        n_act = 0
+        npx, npy = orc.grid(prm0)
+        for p in range(npx * npy):
+            x, y, w, h = orc.patch_rect(prm0, p % npx, p // npx)
+            k = int(((ev0["x"] >= x) & (ev0["x"] < x + w) & (ev0["y"] >= y) & (ev0["y"] < y + h)).sum())
+            n_act += k if k > prm0.min_events else 0
+        evals = int(summ.num_evals_cost + summ.num_evals_jac)
+        legs["solve_independent"] = {
+            "value": n_act * evals / dt / 1e6, "unit": "Mevents/s", "cores": 1,
+            "sample": "1 per-patch solve of 1 window of %s (%d scored events x <= %d evaluations, %.2f s; "
+                      "upper bound: every patch charged the longest patch's evaluation count)"
+                      % (synth.CONFIGS[0]["name"], n_act, evals, dt)}
+    except Exception as exc:  # a reported extra
+        legs["solve_independent"] = {"error": repr(exc)}
+    # (iii) the integer count images alone (feature_detector.cpp:433-463 warped, :466-482 un-warped)
+    try:
+        reps_c = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < min(3.0, seconds_budget):
+            orc.final_count_image(ev, prm, flows)
+            reps_c += 1
+        dt = time.perf_counter() - t0
+        legs["count_image_warped"] = {"value": len(ev) * reps_c / dt / 1e6, "unit": "Mevents/s", "cores": 1,
+                                      "sample": "%d warped count images of 1 window of %s" % (reps_c, cfg["name"])}
+        reps_c = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < min(2.0, seconds_budget):
+            orc.integrate_events(ev, cfg["image"][0], cfg["image"][1])
+            reps_c += 1
+        dt = time.perf_counter() - t0
+        legs["count_image_integrated"] = {"value": len(ev) * reps_c / dt / 1e6, "unit": "Mevents/s", "cores": 1,
+                                          "sample": "%d un-warped count images of 1 window of %s" % (reps_c, cfg["name"])}
+    except Exception as exc:
+        legs["count_image"] = {"error": repr(exc)}
+    base["legs"] = legs
+    return base
 
 
 def _cpu_worker(args):
     """One host core: value+Jacobian evaluations of its own synthetic window by the oracle."""
     cfg_idx, window, seconds = args
-    import importlib
     import orc
     synth = importlib.import_module("event-based-odomety_amd.synth")
     cfg = synth.CONFIGS[cfg_idx]
@@ -86,180 +149,378 @@ def cpu_baseline_all_cores(cfg_idx, seconds):
                       % (cores, seconds)}
 
 
+# --------------------------------------------------------------------------------------------
+# launcher
+# --------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD
+    processes (torch.distributed.run) before this process has touched the GPU, relay their output,
+    exit with their code.  Nothing is exec'ed and this process never initialises HIP."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Comm:
+    """The collectives of one run: RCCL ("nccl") on device tensors, or — rehearsal only — gloo on
+    host copies.  world == 1 without EBO_BENCH_FORCE_DIST: no process group at all."""
+
+    def __init__(self, torch, rank, world, local, rehearse, force):
+        self.torch, self.rank, self.world = torch, rank, world
+        self.active = world > 1 or force
+        self.backend = None
+        if self.active:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            self.backend = "gloo" if rehearse else "nccl"
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    @property
+    def coll_device(self):
+        return "cpu" if self.backend == "gloo" else "cuda"
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.active:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, value, op):
+        if not self.active:
+            return float(value)
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.coll_device)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+    def allgather_rows(self, exchange, t_local, counts, out):
+        """ONE all-gather of per-rank row blocks (max-padded when unequal) into `out`."""
+        if not self.active:
+            out.copy_(t_local)
+            return out
+        if self.backend == "gloo":
+            res = exchange.allgather_rows(t_local.cpu(), counts)
+            out.copy_(res)
+            return out
+        return exchange.allgather_rows(t_local, counts, out=out)
+
+    def allgather_tracks(self, exchange, local):
+        if not self.active:
+            return local, [len(local)]
+        return exchange.allgather_tracks(local, device=self.coll_device)
+
+    def close(self):
+        if self.active:
+            self.dist.destroy_process_group()
+
+
+def bucket_rows(ev, cfg, row_b, row_e):
+    """The events of grid rows [row_b, row_e) of one window, grouped by patch in grid order
+    (time order kept inside a patch, as feature_detector.cpp:348-355 leaves them):
+    -> (events, per-patch counts [rows * npx])."""
+    iw, ih = cfg["image"]
+    pw, ph = cfg["patch"]
+    npx, npy = iw // pw, ih // ph
+    gx = np.minimum(ev["x"] // pw, npx - 1)
+    gy = np.minimum(ev["y"] // ph, npy - 1)
+    sel = np.flatnonzero((gy >= row_b) & (gy < row_e))
+    pid = (gy[sel] - row_b) * npx + gx[sel]
+    order = np.argsort(pid, kind="stable")
+    counts = np.bincount(pid, minlength=(row_e - row_b) * npx)
+    return ev[sel[order]], counts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE config index (2 = configs[1])")
-    ap.add_argument("--windows", type=int, default=256, help="independent windows per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("auto", "eval", "c4", "replicas"), default="auto")
+    ap.add_argument("--config", type=int, default=3, help="eval / replicas: BASELINE config index (3 = configs[2])")
+    ap.add_argument("--windows", type=int, default=None, help="eval / replicas: independent windows per GPU per step")
+    ap.add_argument("--c4-windows", type=int, default=4, help="c4: windows in flight PER GPU (batch = N x this)")
+    ap.add_argument("--strong", action="store_true", help="c4: keep the batch at --c4-windows windows in total")
+    ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--exchange", action="store_true",
-                    help="N > 1: all-gather (r, J0, J1) after every step (a window sharded over GPUs)")
     args = ap.parse_args()
+    if args.replicas:
+        args.workload = "replicas"
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    workload = args.workload
+    if workload == "auto":
+        workload = "eval" if world == 1 else "c4"
+    if args.steps is None:
+        args.steps = {"eval": 200, "c4": 20, "replicas": 50}[workload]
+    if args.warmup is None:
+        args.warmup = {"eval": 10, "c4": 2, "replicas": 3}[workload]
+    if args.windows is None:
+        args.windows = 64 if args.config >= 3 else 256
+    extras_on = rank == 0 and world == 1 and not args.no_extras and workload == "eval"
+
     cpu_all = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if extras_on:
         try:
             cpu_all = cpu_baseline_all_cores(args.config, min(3.0, args.cpu_seconds))
         except Exception as exc:  # a reported extra, never a reason to lose the bench line
             cpu_all = {"error": repr(exc)}
 
     import torch
-    import torch.distributed as dist
-
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local)
-    # EBO_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, barrier, reductions) with a
-    # single rank: a rehearsal of that path on a one-GPU box
-    use_dist = world > 1 or os.environ.get("EBO_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+    ndev = torch.cuda.device_count()
+    rehearse = os.environ.get("EBO_BENCH_REHEARSE") == "1"
+    if world > ndev and not rehearse:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (EBO_BENCH_REHEARSE=1 shares them, for rehearsal only)"
+                         % (world, ndev))
+    dev = local % ndev if rehearse else local
+    torch.cuda.set_device(dev)
+    # EBO_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, barrier, reductions,
+    # all-gathers) with a single rank: a rehearsal of that path on a one-GPU box
+    comm = Comm(torch, rank, world, dev, rehearse, os.environ.get("EBO_BENCH_FORCE_DIST") == "1")
 
     ebo = importlib.import_module("event-based-odomety_amd")
     synth = importlib.import_module("event-based-odomety_amd.synth")
-    cfg = synth.CONFIGS[args.config]
-
-    # ---- synthetic stream: `windows` windows per rank, distinct per rank ---------
-    Wn = args.windows
-    evs, gts = [], []
-    for w in range(Wn):
-        e, g = synth.make_window(args.config, window=rank * Wn + w)
-        evs.append(e)
-        gts.append(g)
-    offsets = np.zeros(Wn + 1, dtype=np.uint64)
-    offsets[1:] = np.cumsum([len(e) for e in evs])
-    ev = np.concatenate(evs)
-    n_events = int(len(ev))
-    gt = np.stack(gts)
-    del evs
-
-    ctx = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
-                      patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,
-                      grad=ebo.GRAD_JET, tv_weight=0.0, max_events=n_events, max_windows=Wn)
+    exchange = importlib.import_module("event-based-odomety_amd.exchange")
     stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_windows(ev, offsets)
-    P = ctx.P
-    active_events = sum(ctx.patch_info(p, w)[0] for w in range(Wn) for p in range(P) if ctx.patch_info(p, w)[1])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    d_flows = torch.from_numpy(gt * 0.5).to("cuda")  # mid-solve candidate flows
-    d_out = torch.zeros((Wn * P, 3), dtype=torch.float64, device="cuda")
-    exchange = use_dist and args.exchange
-    d_all = torch.zeros((world * Wn * P, 3), dtype=torch.float64, device="cuda") if exchange else None
-
-    def step():
-        ctx.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr())
-        if exchange:
-            dist.all_gather_into_tensor(d_all, d_out)
-
-    def barrier():
+    def timed(fn, reps):
+        """average duration of fn's launches by HIP events on the stream they are launched on"""
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
         torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
 
+    # ---------------------------------------------------------------------------------------
+    # workloads: each returns (step, units-per-step fn, kernel timing fn, config dict, cleanup)
+    # ---------------------------------------------------------------------------------------
+    def setup_eval(cfg_idx, Wn, seq):
+        """`Wn` windows of BASELINE config cfg_idx (sequence `seq`: distinct events per rank)."""
+        cfg = synth.CONFIGS[cfg_idx]
+        evs, gts = [], []
+        for w in range(Wn):
+            e, g = synth.make_window(cfg_idx, window=seq * Wn + w)
+            evs.append(e)
+            gts.append(g)
+        offsets = np.zeros(Wn + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([len(e) for e in evs])
+        ev = np.concatenate(evs)
+        gt = np.stack(gts)
+        ctx = ebo.Context(device=dev, image_w=cfg["image"][0], image_h=cfg["image"][1],
+                          patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,
+                          grad=ebo.GRAD_JET, tv_weight=0.0, max_events=len(ev), max_windows=Wn)
+        ctx.set_stream(stream.cuda_stream)
+        ctx.set_windows(ev, offsets)
+        P = ctx.P
+        active = sum(ctx.patch_info(p, w)[0] for w in range(Wn) for p in range(P) if ctx.patch_info(p, w)[1])
+        d_flows = torch.from_numpy(gt * 0.5).to("cuda")  # mid-solve candidate flows
+        d_out = torch.zeros((Wn * P, 3), dtype=torch.float64, device="cuda")
+        return dict(cfg=cfg, ctx=ctx, ev=ev, offsets=offsets, gt=gt, P=P, active=active, n_events=len(ev),
+                    d_flows=d_flows, d_out=d_out)
+
+    def setup_c4(n_ranks, r, windows_total, distinct=4):
+        """BASELINE configs[3] sharded by patch rows: rank r of n_ranks loads, for every window of the
+        batch, the patches of ITS grid rows with the events inside them (ebo_set_patches)."""
+        cfg = synth.CONFIGS[4]
+        iw, ih = cfg["image"]
+        pw, ph = cfg["patch"]
+        npx, npy = iw // pw, ih // ph
+        rows = exchange.shard_counts(npy, n_ranks)
+        b, e = ebo.shard_range(npy, r, n_ranks)
+        _, _, rects = synth.grid_rects(cfg["image"], cfg["patch"])
+        my_rects = rects[b * npx:e * npx]
+        # a few distinct windows, repeated to fill the batch (a window's events are generated by
+        # numpy at ~2 s per 1 M events; each copy has its own buffers and is solved on its own)
+        base = [bucket_rows(synth.make_window(4, window=w)[0], cfg, b, e) for w in range(min(distinct, windows_total))]
+        evs, cnts = [], []
+        for w in range(windows_total):
+            ev_w, c_w = base[w % len(base)]
+            evs.append(ev_w)
+            cnts.append(c_w)
+        ev = np.concatenate(evs) if evs else np.zeros(0, dtype=ebo.EVENT_DTYPE)
+        offs = np.zeros(windows_total * len(my_rects) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(np.concatenate(cnts))
+        n_units = windows_total * len(my_rects)
+        ctx = ebo.Context(device=dev, image_w=iw, image_h=ih, patch_w=pw, patch_h=ph, loss=ebo.LOSS_VARIANCE,
+                          grad=ebo.GRAD_JET, tv_weight=0.0, max_events=max(len(ev), 1), max_windows=max(windows_total, 1))
+        ctx.set_stream(stream.cuda_stream)
+        ctx.set_patches(ev, offs, np.tile(my_rects, (windows_total, 1)))
+        d_sol = torch.zeros((n_units, 2), dtype=torch.float64, device="cuda")
+        d_stats = torch.zeros((n_units, 4), dtype=torch.int32, device="cuda")
+        counts = [windows_total * q * npx for q in rows]
+        d_all = torch.zeros((sum(counts), 2), dtype=torch.float64, device="cuda")
+        n_ev_unit = np.diff(offs.astype(np.int64))
+        return dict(cfg=cfg, ctx=ctx, d_sol=d_sol, d_stats=d_stats, d_all=d_all, counts=counts, rows=rows,
+                    n_units=n_units, n_ev_unit=n_ev_unit, n_events=len(ev), npx=npx, npy=npy,
+                    windows_total=windows_total, opts=ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
+
+    def c4_event_evals(S):
+        st = S["d_stats"].cpu().numpy()
+        return float(((st[:, 1] + st[:, 2]).astype(np.int64) * S["n_ev_unit"]).sum())
+
+    extras = {}
+    roof_kernel = None
+    if workload in ("eval", "replicas"):
+        S = setup_eval(args.config, args.windows, rank)
+        ctx, cfg = S["ctx"], S["cfg"]
+
+        def eval_step():
+            ctx.eval_device(S["d_flows"].data_ptr(), 1, S["d_out"].data_ptr())
+
+        tracks_state = None
+        if workload == "replicas":
+            # the rank's tracked feature patches (the per-feature tracker objective, Optimizer::optimize):
+            # a different number per sequence, so that the track lists are unequal
+            rng = np.random.default_rng(7 + rank)
+            H, Wd = cfg["image"][1], cfg["image"][0]
+            ys, xs = np.mgrid[0:H, 0:Wd].astype(np.float64)
+            img = sum(rng.uniform(-1, 1) * np.exp(-((xs - rng.uniform(0, Wd)) ** 2 + (ys - rng.uniform(0, H)) ** 2)
+                                                  / (2 * rng.uniform(3, 9) ** 2)) for _ in range(40))
+            gx, gy = np.zeros_like(img), np.zeros_like(img)
+            gx[:, 1:-1] = 0.5 * (img[:, 2:] - img[:, :-2])
+            gy[1:-1, :] = 0.5 * (img[2:, :] - img[:-2, :])
+            co = ebo.Context(device=dev, image_w=Wd, image_h=H)
+            co.optimizer_set_grad(gx, gy)
+            n_tr = 100 - 3 * rank
+            rects = np.stack([rng.uniform(5, Wd - 30, n_tr), rng.uniform(5, H - 30, n_tr),
+                              np.full(n_tr, 25.0), np.full(n_tr, 25.0)], 1)
+            nablas = [rng.integers(-3, 4, (25, 25)).astype(np.float64) for _ in range(n_tr)]
+            tracks_state = dict(co=co, rects=rects, nablas=nablas, poses=np.tile([1.0, 0.0, 0.0, 0.0], (n_tr, 1)),
+                                fds=rng.uniform(0, 6.28, n_tr), step=0, mine=np.zeros(0, dtype=ebo.TRACK_DTYPE),
+                                gathered=0, counts=None)
+
+        def step():
+            eval_step()
+            if tracks_state is not None:
+                T = tracks_state
+                poses, _, _ = T["co"].optimizer_solve(T["rects"], T["nablas"], T["poses"], T["fds"], normalize=True)
+                pts = np.zeros(len(poses), dtype=ebo.TRACK_DTYPE)  # Patch::addTrajectoryPosition: new corner + time
+                pts["id"] = np.arange(len(poses)) + 1000 * rank
+                pts["t_us"] = 1_000_000 + 50_000 * T["step"]
+                pts["x"] = T["rects"][:, 0] + 12.5 + poses[:, 2]
+                pts["y"] = T["rects"][:, 1] + 12.5 + poses[:, 3]
+                T["step"] += 1
+                T["mine"] = pts  # the points this step added to the rank's tracks
+                allp, counts = comm.allgather_tracks(exchange, pts)
+                T["gathered"], T["counts"] = len(allp), counts
+
+        units_per_step = float(S["active"])
+        kernel_fn = eval_step
+        roof_kernel = "k_eval3<true>"
+        par = ("windows sharded over %d GPU(s), no data-path collective" % world) if workload == "eval" else (
+            "%d independent sequences, one per GPU; per step one gather of the per-sequence tracks "
+            "(counts + max-padded all-gather)" % world)
+        config = {"workload": cfg["name"] + (" (BASELINE configs[4]: one sequence per GPU)" if workload == "replicas" else ""),
+                  "windows_per_gpu_per_step": args.windows, "events_per_gpu_per_step": S["n_events"],
+                  "scored_events_per_gpu_per_step": S["active"], "patches_per_window": S["P"],
+                  "loss": "variance", "grad": "jet", "step": "one batched value+Jacobian evaluation"
+                  + (" + tracker solve + track gather" if workload == "replicas" else ""), "parallelism": par}
+    else:
+        wt = args.c4_windows if args.strong else args.c4_windows * world
+        S = setup_c4(world, rank, wt)
+        ctx, cfg = S["ctx"], S["cfg"]
+
+        def solve_only():
+            ctx.solve_device(S["opts"], S["d_sol"].data_ptr(), S["d_stats"].data_ptr())
+
+        def step():
+            solve_only()
+            comm.allgather_rows(exchange, S["d_sol"], S["counts"], S["d_all"])
+
+        step()
+        torch.cuda.synchronize()
+        units_per_step = c4_event_evals(S)
+        kernel_fn = solve_only
+        roof_kernel = "k_solve_independent"
+        config = {"workload": cfg["name"] + ", patch rows sharded over %d GPU(s)" % world,
+                  "windows_in_batch": wt, "grid_rows_per_gpu": S["rows"], "patches_per_gpu_per_step": S["n_units"],
+                  "events_per_gpu_per_step": S["n_events"], "event_evaluations_per_gpu_per_step": units_per_step,
+                  "loss": "variance", "grad": "jet",
+                  "step": "device-resident per-patch solve of the shard (ebo_solve_device) + one all-gather of the solved flows",
+                  "parallelism": "patch rows of every window sharded over %d GPU(s), %s all-gather of flows (16 B/patch) per step"
+                                 % (world, "RCCL" if comm.backend == "nccl" else (comm.backend or "no"))}
+
+    # ---- the timed region: W warm-up steps, barrier, EXACTLY K steps, barrier -----------------
     for _ in range(args.warmup):
         step()
-    barrier()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    comm.barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        cnt = torch.tensor([active_events], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_events = float(cnt.item())
-    else:
-        total_events = float(active_events)
+    dt = comm.reduce(dt, "MAX")
+    total_units = comm.reduce(units_per_step, "SUM")
 
-    # ---- dominant kernel: average launch duration by HIP events on ITS stream -----
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record(stream)
-    for _ in range(args.steps):
-        ctx.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr())
-    e1.record(stream)
-    torch.cuda.synchronize()
-    kern_ms = e0.elapsed_time(e1) / args.steps
-    achieved = BYTES_PER_EVENT_EVAL * active_events / (kern_ms * 1e-3) / 1e9
+    # ---- dominant kernel: average launch duration by HIP events on ITS stream -----------------
+    kern_ms = timed(kernel_fn, max(3, args.steps))
+    achieved = BYTES_PER_EVENT_EVAL * units_per_step / (kern_ms * 1e-3) / 1e9
 
-    extras = {}
+    if workload == "replicas" and rank == 0:
+        T = tracks_state
+        extras["track_gather"] = {"records_per_step_all_ranks": T["gathered"], "per_rank": T["counts"]}
+    if workload == "c4" and rank == 0:
+        # the gathered buffer holds every window's flows: rank q's block = its rows of every window
+        got = S["d_all"].cpu().numpy()
+        mine = S["d_sol"].cpu().numpy()
+        lo = sum(S["counts"][:rank])
+        extras["allgather_check"] = bool(np.array_equal(got[lo:lo + len(mine)], mine)) and bool(np.isfinite(got).all())
+        st = S["d_stats"].cpu().numpy()
+        extras["mean_evals_per_patch"] = float((st[:, 1] + st[:, 2])[st[:, 2] > 0].mean())
+
     if cpu_all is not None:
         extras["cpu_baseline_all_cores"] = cpu_all
-    if rank == 0 and world == 1 and not args.no_extras:  # single-GPU diagnostics; ranks of an N > 1 run stay in step
+    if extras_on:  # single-GPU diagnostics; ranks of an N > 1 run stay in step
+        Wn, P, n_events, offsets, ev = args.windows, S["P"], S["n_events"], S["offsets"], S["ev"]
+        d_flows, d_out = S["d_flows"], S["d_out"]
+
+        def rate(n, ms):
+            return n / (ms * 1e-3) / 1e6
+
         # value-only evaluation (the cost-only evaluations of the LM loop)
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(args.steps):
-            ctx.eval_device(d_flows.data_ptr(), 0, d_out.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        extras["value_only_mevents_per_s"] = active_events / (e0.elapsed_time(e1) / args.steps * 1e-3) / 1e6
+        ms = timed(lambda: ctx.eval_device(d_flows.data_ptr(), 0, d_out.data_ptr()), args.steps)
+        extras["value_only_mevents_per_s"] = rate(S["active"], ms)
         # device-resident independent solve of every window (one launch)
         d_sol = torch.zeros((Wn * P, 2), dtype=torch.float64, device="cuda")
         d_stats = torch.zeros((Wn * P, 4), dtype=torch.int32, device="cuda")
         opts = ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT)
         ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
-        torch.cuda.synchronize()
-        e0.record(stream)
-        ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
+        solve_ms = timed(lambda: ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr()), 2)
         st = d_stats.cpu().numpy().reshape(Wn, P, 4)
         ne = np.array([[ctx.patch_info(p, w)[0] for p in range(P)] for w in range(Wn)])
         evals = (st[:, :, 1] + st[:, :, 2]) * ne
-        solve_ms = e0.elapsed_time(e1)
         extras["solve_independent"] = {
-            "ms": solve_ms, "windows": Wn, "mevents_per_s": float(evals.sum()) / (solve_ms * 1e-3) / 1e6,
-            "mean_evals_per_patch": float((st[:, :, 1] + st[:, :, 2])[st[:, :, 2] > 0].mean()),
-        }
-        # integer count image (HBM-bound kernel): warped by the solved flows
-        d_img = torch.zeros((Wn, cfg["image"][1], cfg["image"][0]), dtype=torch.float64, device="cuda")
-        ctx.count_image_device(ebo.COUNT_WARPED, d_sol.data_ptr(), d_img.data_ptr())
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(10):
-            ctx.count_image_device(ebo.COUNT_WARPED, d_sol.data_ptr(), d_img.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        cms = e0.elapsed_time(e1) / 10
-        img_bytes = d_img.numel() * 8
-        extras["count_image_warped"] = {
-            "ms": cms, "mevents_per_s": n_events / (cms * 1e-3) / 1e6,
-            "gbs_algorithmic": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9,
-            "hbm_frac": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        }
-        # un-warped count image (integrateEvents, feature_detector.cpp:466-482)
-        ctx.count_image_device(ebo.COUNT_INTEGRATED, 0, d_img.data_ptr())
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(10):
-            ctx.count_image_device(ebo.COUNT_INTEGRATED, 0, d_img.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        cms = e0.elapsed_time(e1) / 10
-        extras["count_image_integrated"] = {
-            "ms": cms, "mevents_per_s": n_events / (cms * 1e-3) / 1e6,
-            "gbs_algorithmic": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9,
-            "hbm_frac": (8 * n_events + img_bytes) / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        }
-        # single-window latency (one 50k-event window, one launch)
-        c1 = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
+            "ms": solve_ms, "windows": Wn, "mevents_per_s": rate(float(evals.sum()), solve_ms),
+            "mean_evals_per_patch": float((st[:, :, 1] + st[:, :, 2])[st[:, :, 2] > 0].mean())}
+        # single-window latency (one window, one launch)
+        c1 = ebo.Context(device=dev, image_w=cfg["image"][0], image_h=cfg["image"][1],
                          patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,
                          tv_weight=0.0, max_events=int(offsets[1]), max_windows=1)
         c1.set_stream(stream.cuda_stream)
@@ -268,13 +529,7 @@ def main():
         o1 = torch.zeros((P, 3), dtype=torch.float64, device="cuda")
         for _ in range(5):
             c1.eval_device(f1.data_ptr(), 1, o1.data_ptr())
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(200):
-            c1.eval_device(f1.data_ptr(), 1, o1.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        extras["single_window_eval_us"] = e0.elapsed_time(e1) / 200 * 1e3
+        extras["single_window_eval_us"] = timed(lambda: c1.eval_device(f1.data_ptr(), 1, o1.data_ptr()), 200) * 1e3
         c1.close()
         # window set-up: host counting sort + 8 B/event upload  vs  24 B/event upload + device
         # bucketing  vs  device bucketing of events already resident (ebo_set_windows_device)
@@ -283,11 +538,13 @@ def main():
         ctx.set_windows(ev, offsets)
         t_host = time.perf_counter() - t0
         os.environ.pop("EBO_BUCKET")
+        ctx.set_windows(ev, offsets)
         t0 = time.perf_counter()
         ctx.set_windows(ev, offsets)
         t_dev = time.perf_counter() - t0
         d_raw = torch.from_numpy(ev.view(np.uint8).reshape(-1, 24)).to("cuda")
         torch.cuda.synchronize()
+        ctx.set_windows_device(d_raw.data_ptr(), offsets)
         t0 = time.perf_counter()
         ctx.set_windows_device(d_raw.data_ptr(), offsets)
         t_res = time.perf_counter() - t0
@@ -296,56 +553,86 @@ def main():
             "raw_upload_plus_device_bucketing": n_events / t_dev / 1e6,
             "device_bucketing_resident_events": n_events / t_res / 1e6}
         del d_raw
-        # the reference's own default objective (edge / structure-tensor loss), value+Jacobian
-        We = min(Wn, 64)
-        ce = ebo.Context(device=local, image_w=cfg["image"][0], image_h=cfg["image"][1],
-                         patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_EDGE,
-                         tv_weight=0.0, max_events=int(offsets[We]), max_windows=We)
-        ce.set_stream(stream.cuda_stream)
-        ce.set_windows(ev[: int(offsets[We])], offsets[: We + 1])
-        fe = d_flows[:We].contiguous()
-        oe = torch.zeros((We * P, 3), dtype=torch.float64, device="cuda")
-        for _ in range(2):
-            ce.eval_device(fe.data_ptr(), 1, oe.data_ptr())
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(10):
-            ce.eval_device(fe.data_ptr(), 1, oe.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        ems = e0.elapsed_time(e1) / 10
-        extras["edge_loss_value_jacobian"] = {"ms": ems, "windows": We,
-                                              "mevents_per_s": int(offsets[We]) / (ems * 1e-3) / 1e6}
-        ce.close()
-        # the 1280x720 stream of BASELINE configs[3] (1024 patches, 1 M events per window) on this
-        # one GPU: same kernel, 8 windows per launch
-        c4 = synth.CONFIGS[4]
-        ev4, off4, gt4 = synth.make_stream(4, 8)
-        cc = ebo.Context(device=local, image_w=c4["image"][0], image_h=c4["image"][1], patch_w=c4["patch"][0],
-                         patch_h=c4["patch"][1], loss=ebo.LOSS_VARIANCE, tv_weight=0.0, max_events=len(ev4),
-                         max_windows=8)
-        cc.set_stream(stream.cuda_stream)
-        cc.set_windows(ev4, off4)
-        f4 = torch.from_numpy(gt4 * 0.5).to("cuda")
-        o4 = torch.zeros((8 * cc.P, 3), dtype=torch.float64, device="cuda")
-        for _ in range(2):
-            cc.eval_device(f4.data_ptr(), 1, o4.data_ptr())
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(10):
-            cc.eval_device(f4.data_ptr(), 1, o4.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        ms4 = e0.elapsed_time(e1) / 10
-        extras["c4_1280x720_value_jacobian"] = {"ms": ms4, "windows": 8, "patches_per_window": cc.P,
-                                                "mevents_per_s": len(ev4) / (ms4 * 1e-3) / 1e6}
-        cc.close()
-        del ev4, f4, o4
+
+        def eval_extra(ci, wn, loss, label, reps=10, cfgd=None):
+            """value+Jacobian evaluation of `wn` windows of config ci with `loss`"""
+            c = cfgd or synth.CONFIGS[ci]
+            evx, offx, gtx = synth.make_stream(ci if cfgd is None else cfgd, wn)
+            cx = ebo.Context(device=dev, image_w=c["image"][0], image_h=c["image"][1], patch_w=c["patch"][0],
+                             patch_h=c["patch"][1], loss=loss, tv_weight=0.0, max_events=len(evx), max_windows=wn)
+            cx.set_stream(stream.cuda_stream)
+            cx.set_windows(evx, offx)
+            fx = torch.from_numpy(gtx * 0.5).to("cuda")
+            ox = torch.zeros((wn * cx.P, 3), dtype=torch.float64, device="cuda")
+            for _ in range(2):
+                cx.eval_device(fx.data_ptr(), 1, ox.data_ptr())
+            msx = timed(lambda: cx.eval_device(fx.data_ptr(), 1, ox.data_ptr()), reps)
+            extras[label] = {"ms": msx, "windows": wn, "patches_per_window": cx.P, "mevents_per_s": rate(len(evx), msx)}
+            cx.close()
+
+        # the other BASELINE sizes with the same kernel, and the reference's own default objective
+        # (edge / structure-tensor loss) on C2 and on the reference-default grid
+        eval_extra(2, 256, ebo.LOSS_VARIANCE, "c2_240x180_value_jacobian")
+        eval_extra(4, 8, ebo.LOSS_VARIANCE, "c4_1280x720_value_jacobian")
+        eval_extra(2, 64, ebo.LOSS_EDGE, "edge_loss_value_jacobian")
+        eval_extra(3, 16, ebo.LOSS_EDGE, "edge_loss_value_jacobian_c3")
+        rcfg = dict(name="reference default", image=(240, 180), patch=(20, 20), events=15000, index=0)
+        eval_extra(0, 256, ebo.LOSS_EDGE, "edge_loss_value_jacobian_reference_default", cfgd=rcfg)
+
+        # integer count images (the HBM-bound kernels) on working sets >= 1 GiB: a few distinct
+        # windows repeated (every copy has its own events and its own image in HBM)
+        def count_extra(ci, distinct, copies, label):
+            c = synth.CONFIGS[ci]
+            evx, offx, gtx = synth.make_stream(ci, distinct)
+            wn = distinct * copies
+            ev_all = np.tile(evx, copies)
+            off_all = np.zeros(wn + 1, dtype=np.uint64)
+            per = np.diff(offx.astype(np.int64))
+            off_all[1:] = np.cumsum(np.tile(per, copies))
+            cx = ebo.Context(device=dev, image_w=c["image"][0], image_h=c["image"][1], patch_w=c["patch"][0],
+                             patch_h=c["patch"][1], loss=ebo.LOSS_VARIANCE, tv_weight=0.0, max_events=len(ev_all),
+                             max_windows=wn)
+            cx.set_stream(stream.cuda_stream)
+            cx.set_windows(ev_all, off_all)
+            n_ev = len(ev_all)
+            del ev_all
+            fl = torch.from_numpy(np.tile(gtx, (copies, 1, 1))).to("cuda")  # ground-truth flows = a solved window's
+            d_img = torch.zeros((wn, c["image"][1], c["image"][0]), dtype=torch.float64, device="cuda")
+            nbytes = 8 * n_ev + d_img.numel() * 8
+            res = {"windows": wn, "working_set_bytes": nbytes}
+            for mode, name, aux in ((ebo.COUNT_WARPED, "warped", fl.data_ptr()), (ebo.COUNT_INTEGRATED, "integrated", 0)):
+                cx.count_image_device(mode, aux, d_img.data_ptr())
+                msx = min(timed(lambda: cx.count_image_device(mode, aux, d_img.data_ptr()), 10) for _ in range(3))
+                res[name] = {"ms": msx, "mevents_per_s": rate(n_ev, msx), "gbs_algorithmic": nbytes / (msx * 1e-3) / 1e9,
+                             "hbm_frac": nbytes / (msx * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            extras[label] = res
+            cx.close()
+            del d_img, fl
+
+        count_extra(2, 128, 12, "count_image_c2")   # 1536 windows: 1.15 GB
+        count_extra(3, 32, 16, "count_image_c3")    # 512 windows: 1.19 GB
+        count_extra(4, 4, 18, "count_image_c4")     # 72 windows: 1.11 GB
+
+        # the N > 1 default workload on this one GPU (the same step: whole grid = one shard, a
+        # self-copy in place of the all-gather): the per-GPU reference the scaling runs compare with
+        S4 = setup_c4(1, 0, args.c4_windows)
+
+        def c4_step():
+            S4["ctx"].solve_device(S4["opts"], S4["d_sol"].data_ptr(), S4["d_stats"].data_ptr())
+            S4["d_all"].copy_(S4["d_sol"])
+
+        c4_step()
+        ms4 = timed(c4_step, 5)
+        ee = c4_event_evals(S4)
+        extras["c4_sharded_solve_step_1gpu"] = {"ms": ms4, "windows": args.c4_windows, "event_evaluations": ee,
+                                                "mevents_per_s": rate(ee, ms4)}
+        S4["ctx"].close()
+        del S4
+
         # the reference's own call (240x180, 20x20 patches, 15 k events, edge loss, TV-coupled
         # global LM: FeatureDetector::compensateEventsContrast as shipped), 64 windows in lock step
-        rcfg = dict(name="reference default", image=(240, 180), patch=(20, 20), events=15000, index=0)
         rev, roff, _ = synth.make_stream(rcfg, 64)
-        cr = ebo.Context(device=local, image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE,
+        cr = ebo.Context(device=dev, image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE,
                          max_events=len(rev), max_windows=64)
         cr.set_windows(rev, roff)
         cr.solve(ebo.default_solver())
@@ -363,7 +650,7 @@ def main():
         gx, gy = np.zeros_like(img), np.zeros_like(img)
         gx[:, 1:-1] = 0.5 * (img[:, 2:] - img[:, :-2])
         gy[1:-1, :] = 0.5 * (img[2:, :] - img[:-2, :])
-        co = ebo.Context(device=local, image_w=240, image_h=180)
+        co = ebo.Context(device=dev, image_w=240, image_h=180)
         co.optimizer_set_grad(gx, gy)
         rects = np.stack([rng.uniform(5, 210, 100), rng.uniform(5, 150, 100), np.full(100, 25.0), np.full(100, 25.0)], 1)
         nablas = [rng.integers(-3, 4, (25, 25)).astype(np.float64) for _ in range(100)]
@@ -376,39 +663,37 @@ def main():
         co.close()
 
     if rank == 0:
-        base = cpu_baseline(synth, args.config, args.cpu_seconds) if world == 1 else None
+        base = cpu_baseline(synth, args.config if workload != "c4" else 3, args.cpu_seconds) if world == 1 else None
         # HBM traffic of the dominant kernel per launch, from the committed PMC profile of
         # this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            t = json.load(open(tpath))
-            if t.get("workload") == cfg["name"] and t.get("windows") == Wn:
-                traffic = t.get("eval_kernel_hbm_bytes_per_launch")
-        value = total_events * args.steps / dt / 1e6
+            for t in json.load(open(tpath)).get("kernels", []):
+                if (t.get("kernel") == roof_kernel and t.get("workload") == cfg["name"]
+                        and t.get("windows") == config.get("windows_per_gpu_per_step")):
+                    traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
+        value = total_units * args.steps / dt / 1e6
         line = {
-            "metric": "Mevents/s warped+scored (value+Jacobian of the variance-contrast objective)",
+            "metric": "Mevents/s warped+scored (value+Jacobian of the variance-contrast objective)"
+                      if workload != "c4" else "Mevents/s warped+scored (event-evaluations of the per-patch solves)",
             "value": value, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"], "windows_per_gpu_per_step": Wn,
-                       "events_per_gpu_per_step": n_events, "scored_events_per_gpu_per_step": active_events,
-                       "patches_per_window": P, "loss": "variance", "grad": "jet",
-                       "parallelism": "windows sharded over %d GPU(s)%s" % (
-                           world, ", RCCL all-gather of (r,J) per step" if exchange
-                           else (", no data-path collective" if world > 1 else ""))},
+            "scaling": "strong" if (workload == "c4" and args.strong) else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "config": config,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_eval3<true>", "kernel_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": roof_kernel, "kernel_ms": kern_ms,
                          "note": "algorithmic 8 B/event-evaluation; the kernel is bound by LDS "
                                  "atomics + f64 VALU, not HBM (DESIGN.md section 4)"},
             "cpu_baseline": base,
             "extras": extras,
         }
-        print(json.dumps(line))
+        if rehearse or (comm.active and world == 1):
+            line["rehearsal"] = "N > 1 code path on shared GPU(s) over %s: not a scaling measurement" % (comm.backend,)
+        print(json.dumps(line), flush=True)
     ctx.close()
-    if use_dist:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+"""The N > 1 path through the HIP kernels with more than one process: ranks share the box's one
+GPU (at most 3 processes touch it), collectives over gloo (RCCL needs one device per rank; its
+1-rank path is tests/test_gpu_comm.py).  What an 8-GPU node runs differs in the transport only."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _torchrun(world, port, script, *argv, env=None, timeout=900):
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + [str(a) for a in argv]
+    return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("config,world,n_windows", [(2, 2, 3), (0, 3, 2)])
+def test_sharded_device_solve_and_gather_equals_one_process(tmp_path, ebo, synth, config, world, n_windows):
+    iters = 8
+    res = _torchrun(world, 29540 + world, os.path.join(HERE, "mp_gpu_worker.py"), tmp_path, config, n_windows, iters)
+    assert res.returncode == 0, res.stderr[-3000:]
+    cfg = synth.CONFIGS[config]
+    evs, offs = [], [0]
+    for w in range(n_windows):
+        ev, _ = synth.make_window(config, window=w, n_events=min(cfg["events"], 40000))
+        evs.append(ev)
+        offs.append(offs[-1] + len(ev))
+    ev = np.concatenate(evs)
+    with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                     patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE, tv_weight=0.0, max_events=len(ev),
+                     max_windows=n_windows) as c:
+        c.set_windows(ev, offs)
+        whole, _ = c.solve(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=iters)
+        act = np.array([[c.patch_info(p, w)[1] for p in range(c.P)] for w in range(n_windows)])
+    first = np.load(os.path.join(str(tmp_path), "flows_rank0.npy"))
+    for r in range(1, world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "flows_rank%d.npy" % r)), first)  # every rank: all flows
+    assert first.shape == whole.shape
+    np.testing.assert_allclose(first[act], whole[act], rtol=0, atol=1e-9)
+    assert np.all(first[~act] == 0)
+
+
+@pytest.mark.parametrize("extra", [[], ["--replicas", "--windows", "4"]])
+def test_bench_runs_at_two_ranks_without_a_launcher(extra):
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun around it): it spawns its own
+    ranks before touching the GPU and prints ONE JSON line naming the N > 1 workload."""
+    env = dict(os.environ, EBO_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--c4-windows", "1"] + extra
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "rehearsal" in line
+    if extra:
+        assert "configs[4]" in line["config"]["workload"]
+        assert line["extras"]["track_gather"]["per_rank"] == [100, 97]
+    else:
+        assert "patch rows sharded over 2" in line["config"]["workload"]
+        assert line["config"]["grid_rows_per_gpu"] == [16, 16]
+        assert line["extras"]["allgather_check"] is True
