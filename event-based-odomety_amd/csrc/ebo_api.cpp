@@ -231,7 +231,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,1024]");
 	}
-	const size_t headerBytes = (168 + 512) * sizeof(double);  // kEdgeHeader
+	const size_t headerBytes = (168 + 1024) * sizeof(double);  // kEdgeHeader
 	const size_t canvasPx = static_cast<size_t>(9) * c->max_rw * c->max_rh;
 	// Two LDS layouts (ebo_edge.inc): I, E, A (f64) + cnt (i32) = 28 B per pixel with the
 	// separable tensor filter, one 1024-lane workgroup per CU; or, when the whole canvas then
@@ -276,7 +276,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 		L.cap_px = std::min(L.cap_px, 8 * L.block);
 	}
 	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx;
-	L.scratch_stride = (canvasPx * bytesPerPx + 255) & ~static_cast<size_t>(255);
+	L.scratch_stride = (canvasPx * (bytesPerPx + 1) + 256 + 255) & ~static_cast<size_t>(255);  // I, E, A, cnt + the argmax list (canvasPx / 4 + 64 ints)
 	L.d_scratch = nullptr;
 	if (static_cast<size_t>(L.cap_px) < canvasPx)
 	{

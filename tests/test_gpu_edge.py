@@ -168,3 +168,22 @@ def test_edge_independent_solve_lockstep(ebo, orc, synth, iters):
         assert summ[0].iterations == so.iterations
         assert summ[0].num_evals_jac == so.num_evals_jac
         assert summ[0].num_evals_cost == so.num_evals_cost
+
+
+@pytest.mark.parametrize("config,windows", [(0, 16), (2, 4), (3, 2)])
+def test_edge_jacobian_is_bit_reproducible(ebo, synth, config, windows):
+    """The adjoint image of the reverse pass is accumulated in exact fixed point on a per-unit grid
+    (integer LDS atomics commute), so value AND Jacobian are identical bits run to run, whatever
+    order the workgroup's atomics retire in."""
+    cfg = synth.CONFIGS[config]
+    ev, offsets, gt = synth.make_stream(config, windows)
+    with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                     patch_h=cfg["patch"][1], loss=ebo.LOSS_EDGE, tv_weight=0.0, max_events=len(ev),
+                     max_windows=windows) as c:
+        c.set_windows(ev, offsets)
+        for scale in (0.0, 0.5, 1.0):
+            r0, J0 = c.eval(gt * scale)
+            assert np.isfinite(J0).all() and np.abs(J0).max() > 0
+            for _ in range(4):
+                r, J = c.eval(gt * scale)
+                assert np.array_equal(r, r0) and np.array_equal(J, J0)
