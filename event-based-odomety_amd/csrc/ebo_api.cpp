@@ -212,18 +212,13 @@ int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
 
 // Edge loss (contrast_functor.h:152-277): one workgroup per unit, arrays in LDS, a
 // per-unit global slice as fallback for boxes that do not fit.
-int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out)
+// Geometry of an edge-loss launch (LDS layout, workgroup size, global fallback slices, tensor
+// weights): shared by the batched evaluation (k_eval_edge) and the device-resident solve (k_solve_edge).
+int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 {
-	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
-	EdgeLaunch L;
-	L.d_modes = c->modes_active;
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
-	L.d_flows = d_flows;
-	L.want_jac = (want_jac && !central) ? 1 : 0;
-	L.flow_sets = central ? 5 : 1;
-	L.fd_step = central ? c->prm.fd_step : 0.0;
 	// one workgroup per CU (LDS-limited): a big workgroup is the only source of waves
 	// (measured, C2 x 64 windows: 256 threads 2.1, 512: 2.8, 1024: 3.3 Gevents/s)
 	L.block = static_cast<int>(env_size("EBO_EDGE_BLOCK", 0));
@@ -309,7 +304,6 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 		return rc;
 	}
 	L.d_sets = c->d_partials;
-	L.d_out = d_out;
 	L.c = make_consts(c);
 	// weights exactly as the reference builds them (:193-202): gaussian(0, 0, j, i, sigmaST)
 	const double sig = c->prm.k.sigma_st;
@@ -331,6 +325,24 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	L.ec.mean_threshold = 0.0001;
 	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
 	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 7));  // forms of the separable tensor filter (see EdgeConsts / ebo_edge.inc)
+	return EBO_OK;
+}
+
+int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out)
+{
+	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
+	EdgeLaunch L;
+	L.d_modes = c->modes_active;
+	L.d_flows = d_flows;
+	L.want_jac = (want_jac && !central) ? 1 : 0;
+	L.flow_sets = central ? 5 : 1;
+	L.fd_step = central ? c->prm.fd_step : 0.0;
+	L.d_out = d_out;
+	int rc = edge_launch_setup(c, L);
+	if (rc)
+	{
+		return rc;
+	}
 	if (launch_eval_edge(L, c->stream))
 	{
 		return c->hip(hipGetLastError(), "edge eval launch");
@@ -748,13 +760,31 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	{
 		return c->fail(EBO_ERR_STATE, "no window loaded");
 	}
-	if (c->prm.loss != EBO_LOSS_VARIANCE)
-	{
-		return c->fail(EBO_ERR_UNSUPPORTED, "device solver is built for EBO_LOSS_VARIANCE");
-	}
 	if (c->prm.grad != EBO_GRAD_JET)
 	{
 		return c->fail(EBO_ERR_UNSUPPORTED, "device solver is built for EBO_GRAD_JET");
+	}
+	if (c->prm.loss == EBO_LOSS_EDGE)
+	{
+		// the reference's own objective (calculateEdgeLoss): the same launch geometry as its
+		// batched evaluation, the whole per-patch LM inside the workgroup
+		EdgeLaunch E;
+		E.d_modes = nullptr;
+		E.d_flows = nullptr;
+		E.want_jac = 1;
+		E.flow_sets = 1;
+		E.fd_step = 0.0;
+		E.d_out = nullptr;
+		int rce = edge_launch_setup(c, E);
+		if (rce)
+		{
+			return rce;
+		}
+		if (launch_solve_edge(E, make_solve_consts(o), d_flows_out, d_stats, c->stream))
+		{
+			return c->hip(hipGetLastError(), "edge solve launch");
+		}
+		return EBO_OK;
 	}
 	SolveLaunch L;
 	L.d_events = c->d_events;
@@ -1202,7 +1232,20 @@ int solve_independent_lockstep(ebo_ctx* c, const ebo_solver_opts* o, double* flo
 
 int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summary* summary)
 {
-	if (c->prm.loss != EBO_LOSS_VARIANCE || c->prm.grad != EBO_GRAD_JET)
+	// device-resident per-patch LM for both losses (forward-mode-equivalent Jacobians);
+	// central differences and EBO_SOLVE_EDGE=lockstep (A/B) run host LMs over batched evaluations
+	// Edge loss, measured (tools/time_edge_solve.py): one reference-default window 3.5 ms on the
+	// device against 5.2 ms in lock step (67 evaluations = 67 round trips); 256 windows 198 against
+	// 194 ms; C2 x 64 windows 81 against 66-72 ms (the batched value-only kernel is the faster one and
+	// the hardware balances uneven patches).  So: the device solve below 2048 units, lock step above;
+	// EBO_SOLVE_EDGE=device / lockstep forces one.  ebo_solve_device is always the device solve.
+	const char* edgeMode = std::getenv("EBO_SOLVE_EDGE");
+	bool lockstepEdge = c->prm.loss == EBO_LOSS_EDGE && c->n_flows() >= 2048;
+	if (c->prm.loss == EBO_LOSS_EDGE && edgeMode && *edgeMode)
+	{
+		lockstepEdge = std::strcmp(edgeMode, "lockstep") == 0;
+	}
+	if (c->prm.grad != EBO_GRAD_JET || lockstepEdge)
 	{
 		return solve_independent_lockstep(c, o, flows_out, summary);
 	}

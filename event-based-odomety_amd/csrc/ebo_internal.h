@@ -138,6 +138,7 @@ struct EdgeLaunch
 	EdgeConsts ec;
 };
 int launch_eval_edge(const EdgeLaunch& L, void* stream);
+int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows_out, int32_t* d_stats, void* stream);
 
 struct SolveLaunch
 {

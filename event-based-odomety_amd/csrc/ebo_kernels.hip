@@ -841,6 +841,267 @@ __device__ __forceinline__ void eval_unit(const uint64_t* __restrict__ ev, const
 	variance_from_sums(S, wantJac, m0, m1, c.max_res, r, j0, j1);
 }
 
+// The whole trust-region LM of ONE 2-parameter, 1-residual problem (the per-patch problem of
+// EBO_SOLVE_INDEPENDENT; Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy with the options
+// of feature_detector.cpp:401-410) as a resumable state machine, replicated in every thread of the
+// workgroup (uniform control flow).  The kernel owns ONE evaluation site:
+//     lm.begin();  do { evaluate(lm.q0, lm.q1, lm.qJac) -> r, J0, J1 } while (lm.advance(r, J0, J1, o));
+// (three inlined copies of an objective as large as the edge loss made the register allocator
+// spill several hundred VGPRs).  Value-only for the cost at a candidate, value + Jacobian after an
+// accepted step -- the sequence Ceres follows.
+struct LmUnit
+{
+	// the evaluation wanted next
+	double q0, q1;
+	bool qJac;
+	// results
+	double best0, best1;
+	int iteration, evalsCost, evalsJac, termination;
+	// solver state
+	int phase;  // 0: first evaluation, 1: cost at a candidate, 2: Jacobian at an accepted point
+	double x0, x1, f, J0, J1, xCost, g0, g1, sc0, sc1, j0, j1, xNorm, gradMax, minimumCost;
+	double seMinimum, seCurrent, seReference, seCandidate, seAccRef, seAccCand;
+	int seNumNonmono;
+	double radius, decreaseFactor, d0, d1;
+	bool reuseDiagonal, lastSuccessful;
+	int numInvalid;
+	double c0, c1, modelCostChange, candCost, quality;
+
+	__device__ __forceinline__ void begin()
+	{
+		best0 = best1 = 0.0;
+		iteration = evalsCost = evalsJac = 0;
+		termination = 1;
+		phase = 0;
+		x0 = x1 = 0.0;  // feature_detector.cpp:318-326
+		q0 = q1 = 0.0;
+		qJac = true;
+	}
+
+	// the loop of TrustRegionMinimizer from its top to the next evaluation; false = finished
+	__device__ __forceinline__ bool next_step(const SolveConsts& o)
+	{
+		for (;;)
+		{
+			if (lastSuccessful && xCost < minimumCost)
+			{
+				minimumCost = xCost;
+				best0 = x0;
+				best1 = x1;
+			}
+			if (iteration >= o.max_num_iterations)
+			{
+				termination = 1;
+				return false;
+			}
+			if (lastSuccessful && gradMax <= o.gradient_tolerance)
+			{
+				termination = 0;
+				return false;
+			}
+			if (radius < o.min_radius)
+			{
+				termination = 0;
+				return false;
+			}
+			iteration++;
+			lastSuccessful = false;
+
+			if (!reuseDiagonal)
+			{
+				d0 = fmin(fmax(j0 * j0, o.min_lm_diagonal), o.max_lm_diagonal);
+				d1 = fmin(fmax(j1 * j1, o.min_lm_diagonal), o.max_lm_diagonal);
+			}
+			const double l0 = sqrt(d0 / radius);
+			const double l1 = sqrt(d1 / radius);
+			reuseDiagonal = true;
+			// (J'J + D'D) y = J'f by Cholesky; step = -y.
+			const double h00 = j0 * j0 + l0 * l0;
+			const double h10 = j1 * j0;
+			const double h11 = j1 * j1 + l1 * l1;
+			bool valid = (h00 > 0.0) && isfinite(h00);
+			double s0 = 0.0, s1 = 0.0;
+			if (valid)
+			{
+				const double L00 = sqrt(h00);
+				const double L10 = h10 / L00;
+				const double dd = h11 - L10 * L10;
+				valid = (dd > 0.0) && isfinite(dd);
+				if (valid)
+				{
+					const double L11 = sqrt(dd);
+					double b0 = (j0 * f) / L00;
+					double b1 = ((j1 * f) - L10 * b0) / L11;
+					b1 = b1 / L11;
+					b0 = (b0 - L10 * b1) / L00;
+					valid = isfinite(b0) && isfinite(b1);
+					s0 = -b0;
+					s1 = -b1;
+				}
+			}
+			modelCostChange = 0.0;
+			if (valid)
+			{
+				const double mr = j0 * s0 + j1 * s1;
+				modelCostChange = 0.0 - mr * (f + mr / 2.0);
+				valid = modelCostChange > 0.0;
+			}
+			if (!valid)
+			{
+				numInvalid++;
+				if (numInvalid >= o.max_invalid)
+				{
+					termination = 2;
+					return false;
+				}
+				radius *= 0.5;
+				reuseDiagonal = true;
+				continue;
+			}
+			numInvalid = 0;
+			c0 = x0 + s0 * sc0;
+			c1 = x1 + s1 * sc1;
+			q0 = c0;
+			q1 = c1;
+			qJac = false;
+			phase = 1;
+			return true;
+		}
+	}
+
+	// takes the result of the evaluation asked for; true = another evaluation is wanted
+	__device__ __forceinline__ bool advance(double r, double a, double b, const SolveConsts& o)
+	{
+		if (phase == 0)
+		{
+			f = r;
+			J0 = a;
+			J1 = b;
+			evalsJac++;
+			xCost = 0.5 * f * f;
+			termination = 1;
+			if (!isfinite(xCost))
+			{
+				termination = 2;
+				return false;
+			}
+			g0 = J0 * f;
+			g1 = J1 * f;
+			sc0 = 1.0;
+			sc1 = 1.0;
+			if (o.jacobi_scaling)
+			{
+				sc0 = 1.0 / (1.0 + sqrt(J0 * J0));
+				sc1 = 1.0 / (1.0 + sqrt(J1 * J1));
+			}
+			j0 = J0 * sc0;
+			j1 = J1 * sc1;
+			xNorm = sqrt(x0 * x0 + x1 * x1);
+			gradMax = fmax(fabs(g0), fabs(g1));
+			minimumCost = xCost;
+			seMinimum = seCurrent = seReference = seCandidate = xCost;
+			seAccRef = seAccCand = 0.0;
+			seNumNonmono = 0;
+			radius = o.initial_radius;
+			decreaseFactor = 2.0;
+			// iteration zero counts as successful: a start already within the gradient
+			// tolerance converges immediately
+			reuseDiagonal = false;
+			lastSuccessful = true;
+			d0 = d1 = 0.0;
+			numInvalid = 0;
+			return next_step(o);
+		}
+		if (phase == 1)
+		{
+			evalsCost++;
+			candCost = 0.5 * r * r;
+			if (!isfinite(candCost))
+			{
+				candCost = 1.7976931348623157e308;
+			}
+			const double e0 = x0 - c0, e1 = x1 - c1;
+			const double stepNorm = sqrt(e0 * e0 + e1 * e1);
+			if (stepNorm <= o.parameter_tolerance * (xNorm + o.parameter_tolerance))
+			{
+				termination = 0;
+				return false;
+			}
+			const double costChange = xCost - candCost;
+			if (fabs(costChange) <= o.function_tolerance * xCost)
+			{
+				termination = 0;
+				return false;
+			}
+			const double relDec = (seCurrent - candCost) / modelCostChange;
+			const double histDec = (seReference - candCost) / (seAccRef + modelCostChange);
+			quality = fmax(relDec, histDec);
+			if (quality > o.min_relative_decrease)
+			{
+				x0 = c0;
+				x1 = c1;
+				xNorm = sqrt(x0 * x0 + x1 * x1);
+				q0 = x0;
+				q1 = x1;
+				qJac = true;
+				phase = 2;
+				return true;
+			}
+			radius = radius / decreaseFactor;
+			decreaseFactor *= 2.0;
+			reuseDiagonal = true;
+			return next_step(o);
+		}
+		// phase 2: the Jacobian at the accepted point
+		f = r;
+		J0 = a;
+		J1 = b;
+		evalsJac++;
+		xCost = 0.5 * f * f;
+		if (!isfinite(xCost))
+		{
+			termination = 2;
+			return false;
+		}
+		g0 = J0 * f;
+		g1 = J1 * f;
+		j0 = J0 * sc0;
+		j1 = J1 * sc1;
+		gradMax = fmax(fabs(g0), fabs(g1));
+		lastSuccessful = true;
+		const double q = 2.0 * quality - 1.0;
+		radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+		radius = fmin(o.max_radius, radius);
+		decreaseFactor = 2.0;
+		reuseDiagonal = false;
+		seCurrent = candCost;
+		seAccCand += modelCostChange;
+		seAccRef += modelCostChange;
+		if (seCurrent < seMinimum)
+		{
+			seMinimum = seCurrent;
+			seNumNonmono = 0;
+			seCandidate = seCurrent;
+			seAccCand = 0.0;
+		}
+		else
+		{
+			++seNumNonmono;
+			if (seCurrent > seCandidate)
+			{
+				seCandidate = seCurrent;
+				seAccCand = 0.0;
+			}
+		}
+		if (seNumNonmono == o.max_nonmono)
+		{
+			seReference = seCandidate;
+			seAccRef = seAccCand;
+		}
+		return next_step(o);
+	}
+};
+
 template <int FIXED>
 __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __restrict__ events,
 									const Unit* __restrict__ units, int capDoubles,
@@ -855,200 +1116,19 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 
 	if (u.flags & kUnitActive)
 	{
-		double x0 = 0.0, x1 = 0.0;  // feature_detector.cpp:318-326
-		double f, J0, J1;
-		eval_unit<FIXED>(ev, u, x0, x1, true, capDoubles, c, lds, f, J0, J1);
-		evalsJac++;
-		double xCost = 0.5 * f * f;
-		termination = 1;
-		if (!isfinite(xCost))
+		LmUnit lm;
+		lm.begin();
+		double r, a, b;
+		do
 		{
-			termination = 2;
-		}
-		else
-		{
-			double g0 = J0 * f, g1 = J1 * f;
-			double sc0 = 1.0, sc1 = 1.0;
-			if (o.jacobi_scaling)
-			{
-				sc0 = 1.0 / (1.0 + sqrt(J0 * J0));
-				sc1 = 1.0 / (1.0 + sqrt(J1 * J1));
-			}
-			double j0 = J0 * sc0, j1 = J1 * sc1;
-			double xNorm = sqrt(x0 * x0 + x1 * x1);
-			double gradMax = fmax(fabs(g0), fabs(g1));
-			double minimumCost = xCost;
-			double seMinimum = xCost, seCurrent = xCost, seReference = xCost, seCandidate = xCost;
-			double seAccRef = 0.0, seAccCand = 0.0;
-			int seNumNonmono = 0;
-			double radius = o.initial_radius, decreaseFactor = 2.0;
-			// iteration zero counts as successful: a start already within the gradient
-			// tolerance converges immediately
-			bool reuseDiagonal = false, lastSuccessful = true;
-			double d0 = 0.0, d1 = 0.0;
-			int numInvalid = 0;
-
-			for (;;)
-			{
-				if (lastSuccessful && xCost < minimumCost)
-				{
-					minimumCost = xCost;
-					best0 = x0;
-					best1 = x1;
-				}
-				if (iteration >= o.max_num_iterations)
-				{
-					termination = 1;
-					break;
-				}
-				if (lastSuccessful && gradMax <= o.gradient_tolerance)
-				{
-					termination = 0;
-					break;
-				}
-				if (radius < o.min_radius)
-				{
-					termination = 0;
-					break;
-				}
-				iteration++;
-				lastSuccessful = false;
-
-				if (!reuseDiagonal)
-				{
-					d0 = fmin(fmax(j0 * j0, o.min_lm_diagonal), o.max_lm_diagonal);
-					d1 = fmin(fmax(j1 * j1, o.min_lm_diagonal), o.max_lm_diagonal);
-				}
-				const double l0 = sqrt(d0 / radius);
-				const double l1 = sqrt(d1 / radius);
-				reuseDiagonal = true;
-				// (J'J + D'D) y = J'f by Cholesky; step = -y.
-				const double h00 = j0 * j0 + l0 * l0;
-				const double h10 = j1 * j0;
-				const double h11 = j1 * j1 + l1 * l1;
-				bool valid = (h00 > 0.0) && isfinite(h00);
-				double s0 = 0.0, s1 = 0.0;
-				if (valid)
-				{
-					const double L00 = sqrt(h00);
-					const double L10 = h10 / L00;
-					const double dd = h11 - L10 * L10;
-					valid = (dd > 0.0) && isfinite(dd);
-					if (valid)
-					{
-						const double L11 = sqrt(dd);
-						double b0 = (j0 * f) / L00;
-						double b1 = ((j1 * f) - L10 * b0) / L11;
-						b1 = b1 / L11;
-						b0 = (b0 - L10 * b1) / L00;
-						valid = isfinite(b0) && isfinite(b1);
-						s0 = -b0;
-						s1 = -b1;
-					}
-				}
-				double modelCostChange = 0.0;
-				if (valid)
-				{
-					const double mr = j0 * s0 + j1 * s1;
-					modelCostChange = 0.0 - mr * (f + mr / 2.0);
-					valid = modelCostChange > 0.0;
-				}
-				if (!valid)
-				{
-					numInvalid++;
-					if (numInvalid >= o.max_invalid)
-					{
-						termination = 2;
-						break;
-					}
-					radius *= 0.5;
-					reuseDiagonal = true;
-					continue;
-				}
-				numInvalid = 0;
-				const double c0 = x0 + s0 * sc0;
-				const double c1 = x1 + s1 * sc1;
-				double fc, t0, t1;
-				eval_unit<FIXED>(ev, u, c0, c1, false, capDoubles, c, lds, fc, t0, t1);
-				evalsCost++;
-				double candCost = 0.5 * fc * fc;
-				if (!isfinite(candCost))
-				{
-					candCost = 1.7976931348623157e308;
-				}
-				const double e0 = x0 - c0, e1 = x1 - c1;
-				const double stepNorm = sqrt(e0 * e0 + e1 * e1);
-				if (stepNorm <= o.parameter_tolerance * (xNorm + o.parameter_tolerance))
-				{
-					termination = 0;
-					break;
-				}
-				const double costChange = xCost - candCost;
-				if (fabs(costChange) <= o.function_tolerance * xCost)
-				{
-					termination = 0;
-					break;
-				}
-				const double relDec = (seCurrent - candCost) / modelCostChange;
-				const double histDec = (seReference - candCost) / (seAccRef + modelCostChange);
-				const double quality = fmax(relDec, histDec);
-				if (quality > o.min_relative_decrease)
-				{
-					x0 = c0;
-					x1 = c1;
-					xNorm = sqrt(x0 * x0 + x1 * x1);
-					eval_unit<FIXED>(ev, u, x0, x1, true, capDoubles, c, lds, f, J0, J1);
-					evalsJac++;
-					xCost = 0.5 * f * f;
-					if (!isfinite(xCost))
-					{
-						termination = 2;
-						break;
-					}
-					g0 = J0 * f;
-					g1 = J1 * f;
-					j0 = J0 * sc0;
-					j1 = J1 * sc1;
-					gradMax = fmax(fabs(g0), fabs(g1));
-					lastSuccessful = true;
-					const double q = 2.0 * quality - 1.0;
-					radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
-					radius = fmin(o.max_radius, radius);
-					decreaseFactor = 2.0;
-					reuseDiagonal = false;
-					seCurrent = candCost;
-					seAccCand += modelCostChange;
-					seAccRef += modelCostChange;
-					if (seCurrent < seMinimum)
-					{
-						seMinimum = seCurrent;
-						seNumNonmono = 0;
-						seCandidate = seCurrent;
-						seAccCand = 0.0;
-					}
-					else
-					{
-						++seNumNonmono;
-						if (seCurrent > seCandidate)
-						{
-							seCandidate = seCurrent;
-							seAccCand = 0.0;
-						}
-					}
-					if (seNumNonmono == o.max_nonmono)
-					{
-						seReference = seCandidate;
-						seAccRef = seAccCand;
-					}
-				}
-				else
-				{
-					radius = radius / decreaseFactor;
-					decreaseFactor *= 2.0;
-					reuseDiagonal = true;
-				}
-			}
-		}
+			eval_unit<FIXED>(ev, u, lm.q0, lm.q1, lm.qJac, capDoubles, c, lds, r, a, b);
+		} while (lm.advance(r, a, b, o));
+		iteration = lm.iteration;
+		evalsCost = lm.evalsCost;
+		evalsJac = lm.evalsJac;
+		termination = lm.termination;
+		best0 = lm.best0;
+		best1 = lm.best1;
 	}
 	if (threadIdx.x == 0 && !(u.flags & kUnitStray))
 	{
@@ -2687,6 +2767,23 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 		hipLaunchKernelGGL(k_edge_central, dim3((L.n_units + 127) / 128), dim3(128), 0, s, L.d_units,
 						   L.n_units, L.fd_step, L.d_sets, L.d_out);
 	}
+	return check_launch();
+}
+
+int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows_out, int32_t* d_stats, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (L.n_units == 0)
+	{
+		return 0;
+	}
+	auto kern = L.alias_lds ? k_solve_edge<true> : k_solve_edge<false>;
+	if (allow_big_lds(kern, L.lds_bytes))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(kern, dim3(L.n_units), dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units, L.cap_px,
+					   L.d_scratch, L.scratch_stride, d_flows_out, d_stats, L.c, L.ec, o);
 	return check_launch();
 }
 

@@ -151,11 +151,14 @@ def test_reference_configuration_end_to_end(ebo, orc, synth):
         assert np.abs(img - io).sum() <= 0.002 * len(ev)
 
 
+@pytest.mark.parametrize("how", ["device", "lockstep"])
 @pytest.mark.parametrize("iters", [4, 8, 10])
-def test_edge_independent_solve_lockstep(ebo, orc, synth, iters):
-    """Per-patch problems (TV off) with the edge loss: host LMs in lock step, one batched
-    device evaluation per round; capped below the chaos horizon (DESIGN.md section 2),
-    which is shorter for the edge loss: its derivative jumps when a window's argmax moves."""
+def test_edge_independent_solve_lockstep(ebo, orc, synth, monkeypatch, iters, how):
+    """Per-patch problems (TV off) with the edge loss, the reference's own objective: the whole LM
+    in one launch (k_solve_edge, the default) and, for A/B, host LMs in lock step over batched
+    device evaluations; capped below the chaos horizon (DESIGN.md section 2), which is shorter
+    for the edge loss: its derivative jumps when a window's argmax moves."""
+    monkeypatch.setenv("EBO_SOLVE_EDGE", how)
     ev, _ = synth.make_window(0, n_events=15000)
     with ctx_for(ebo, synth, 0, tv_weight=0.0) as c:
         c.set_window(ev)
@@ -168,6 +171,44 @@ def test_edge_independent_solve_lockstep(ebo, orc, synth, iters):
         assert summ[0].iterations == so.iterations
         assert summ[0].num_evals_jac == so.num_evals_jac
         assert summ[0].num_evals_cost == so.num_evals_cost
+
+
+@pytest.mark.parametrize("config,windows", [(0, 8), (2, 2), (3, 1)])
+def test_edge_device_solve_equals_the_lockstep_solve(ebo, synth, monkeypatch, config, windows):
+    """ebo_solve_device with the edge loss (no EBO_ERR_UNSUPPORTED any more): the same flows and
+    per-patch statistics as the host-driven lock-step solve of the same windows, run to run
+    identical bits, also where boxes spill into the global-memory slices (C3's corner patches)."""
+    import ctypes as C
+    cfg = synth.CONFIGS[config]
+    ev, offsets, _ = synth.make_stream(config, windows)
+    hip = C.CDLL("libamdhip64.so")
+    with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                     patch_h=cfg["patch"][1], loss=ebo.LOSS_EDGE, tv_weight=0.0, max_events=len(ev),
+                     max_windows=windows) as c:
+        c.set_windows(ev, offsets)
+        n = windows * c.P
+        d_sol, d_st = C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(d_sol), C.c_size_t(n * 16)) == 0
+        assert hip.hipMalloc(C.byref(d_st), C.c_size_t(n * 16)) == 0
+        opts = ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=8)
+        got = []
+        for _ in range(2):
+            c.solve_device(opts, d_sol.value, d_st.value)
+            c.synchronize()
+            sol, st = np.zeros((windows, c.P, 2)), np.zeros((windows, c.P, 4), dtype=np.int32)
+            assert hip.hipMemcpy(sol.ctypes.data_as(C.c_void_p), d_sol, C.c_size_t(n * 16), 2) == 0
+            assert hip.hipMemcpy(st.ctypes.data_as(C.c_void_p), d_st, C.c_size_t(n * 16), 2) == 0
+            got.append((sol, st))
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+        monkeypatch.setenv("EBO_SOLVE_EDGE", "lockstep")
+        ref, summ = c.solve(opts)
+        sol, st = got[0]
+        np.testing.assert_allclose(sol, ref, rtol=0, atol=1e-9)
+        for w in range(windows):
+            assert st[w, :, 0].max() == summ[w].iterations
+            assert st[w, :, 1].sum() == summ[w].num_evals_cost and st[w, :, 2].sum() == summ[w].num_evals_jac
+        hip.hipFree(d_sol)
+        hip.hipFree(d_st)
 
 
 @pytest.mark.parametrize("config,windows", [(0, 16), (2, 4), (3, 2)])
