@@ -837,6 +837,10 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	{
 		L.max_window_events = std::max<uint64_t>(L.max_window_events, wi.n_events);
 	}
+	for (int w = 0; w < c->n_windows && !L.any_stray; ++w)
+	{
+		L.any_stray = c->units[static_cast<size_t>(w) * (c->P + 1) + c->P].n_ev > 0;
+	}
 	L.d_aux = d_aux;
 	L.d_counts = c->d_counts;
 	L.d_image = d_image;

@@ -173,6 +173,7 @@ struct CountLaunch
 	size_t sorted_cap;               // events either half holds
 	const int32_t* d_unit_maxdt;     // [units] max |t_ref(window) - t| per unit (impl 4's displacement bound)
 	uint64_t max_window_events;
+	int any_stray = 0;    // some window has events outside the sensor (impl 6 counts them in a pass of their own)
 	const void* d_aux;    // flows f64 [Wn][P][2] or field f32 [Wn][H][W][2]
 	int32_t* d_counts;    // [Wn][H][W] scratch, zero on entry, zero on exit
 	double* d_image;      // [Wn][H][W]

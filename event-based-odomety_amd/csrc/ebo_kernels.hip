@@ -1214,6 +1214,8 @@ __global__ void k_count_scatter(const uint64_t* __restrict__ events, const Unit*
 	}
 }
 
+constexpr float kSureBase = 0.499999f;  // 0.5 - 1e-6: slack for the f64 roundings of the reference's own expression
+
 // Destination pixel of one event for the count images; MODE = EBO_COUNT_*.  Returns false
 // when the event contributes nothing (outside the image, or a coordinate the reference's
 // int conversion does not define).  Straight-line code: every lane of a wave runs it.
@@ -1239,18 +1241,20 @@ __device__ __forceinline__ bool count_target(uint64_t rec, bool live, int dtWin,
 			m1 = static_cast<double>(f.y);
 		}
 		// Float first.  The reference's position is fl64(x + fl64(fl64(dtw * scale) * m)); the same
-		// expression in float differs from it by at most 4e-7 |displacement| + 6e-8 |x| (five
-		// roundings of 2^-24 on the product, one on the sum, inputs rounded to float), and
-		// |x| < 2^15.  If the float value is farther than that from every half-integer, both round
-		// to the same pixel, and the double arithmetic (quarter-rate conversions, truncations and
-		// compares: the warped count kernels are instruction-bound on it) is not needed.  Anything
-		// else -- a value near a rounding boundary (0.4 % of the events), huge, infinite or NaN
-		// (comparisons false) -- takes the exact path below.
+		// expression in float differs from it by at most 4e-7 |displacement| + 6e-8 |position| (five
+		// roundings of 2^-24 on the product, one on the sum, inputs rounded to float).  If the float
+		// value is farther than that (+ 1e-6) from every half-integer, both round to the same pixel,
+		// and the double arithmetic (half-rate, conversions, truncations and compares) is not needed.
+		// Anything else -- a value near a rounding boundary (0.04 % of the events at sensor
+		// coordinates: a wave of 64 takes the exact branch 2-3 % of the time; with the position term
+		// bounded by its worst case 2^15 instead, 0.8 % and 40 %), huge, infinite or NaN (comparisons
+		// false) -- takes the exact path below.
 		const float prod = static_cast<float>(dt + dtWin) * static_cast<float>(c.scale);
 		const float px = prod * static_cast<float>(m0), py = prod * static_cast<float>(m1);
 		const float vx = static_cast<float>(x) + px, vy = static_cast<float>(y) + py;
 		const float rx = rintf(vx), ry = rintf(vy);
-		const bool sure = fabsf(vx - rx) < 0.498f - 4e-7f * fabsf(px) && fabsf(vy - ry) < 0.498f - 4e-7f * fabsf(py);
+		const bool sure = fabsf(vx - rx) < kSureBase - 4e-7f * fabsf(px) - 6e-8f * fabsf(vx) &&
+						  fabsf(vy - ry) < kSureBase - 4e-7f * fabsf(py) - 6e-8f * fabsf(vy);
 		if (sure)
 		{
 			nx = static_cast<int>(rx);
@@ -1616,6 +1620,301 @@ __global__ void __launch_bounds__(1024) k_count_units(
 		{
 			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
 			out[p] = static_cast<double>(v);
+		}
+	}
+}
+
+// One event of a unit whose flow is wave-uniform, added to the tile [x0, x0 + tw) x [row0, row0 + th)
+// of the warped count image (feature_detector.cpp:443-455): straight-line code, ONE divergent
+// branch (the exact path) and one predicated LDS add.  The first versions of the count kernels
+// spent more scalar instructions on exec-mask bookkeeping (nested && tests, per-event patch
+// lookups) than vector instructions on the events: ~85 SALU per 64 events against the one scalar
+// unit a CU has.  Float first: the float position differs from the reference's f64 one,
+// fl64(x + fl64(fl64(dtw * scale) * m)), by at most 4e-7 |displacement| + 6e-8 |x|; farther than
+// that from every half-integer both round to the same pixel; the rest (~0.4 % of the events, and
+// anything huge or NaN: comparisons false) takes the f64 expression in the reference's order.
+template <bool U16>
+__device__ __forceinline__ void count_hit_uniform(uint64_t rec, bool live, int dtWin, double m0, double m1, float m0f,
+												   float m1f, float scalef, double scale, int x0, int row0, int tw, int th,
+												   unsigned int* cnt)
+{
+	int x, y, pos, dt;
+	unpack(rec, x, y, pos, dt);
+	const int dtw = dt + dtWin;
+	const float prod = static_cast<float>(dtw) * scalef;
+	const float px = prod * m0f, py = prod * m1f;
+	const float vx = static_cast<float>(x) + px, vy = static_cast<float>(y) + py;
+	const float rx = rintf(vx), ry = rintf(vy);
+	// (bitwise, not &&: no short-circuit branches)
+	const bool sure = (static_cast<int>(fabsf(vx - rx) < kSureBase - 4e-7f * fabsf(px) - 6e-8f * fabsf(vx)) &
+					   static_cast<int>(fabsf(vy - ry) < kSureBase - 4e-7f * fabsf(py) - 6e-8f * fabsf(vy))) != 0;
+	int nx = static_cast<int>(rx), ny = static_cast<int>(ry);
+	if (!sure)
+	{
+		const double d = static_cast<double>(dtw);
+		const double fx = static_cast<double>(x) + d * scale * m0;
+		const double fy = static_cast<double>(y) + d * scale * m1;
+		live = (static_cast<int>(live) & static_cast<int>(convertible(fx)) & static_cast<int>(convertible(fy))) != 0;
+		nx = static_cast<int>(round(live ? fx : 0.0));
+		ny = static_cast<int>(round(live ? fy : 0.0));
+	}
+	const int cx = nx - x0, cy = ny - row0;
+	if (static_cast<int>(live) & static_cast<int>(static_cast<unsigned>(cx) < static_cast<unsigned>(tw)) &
+		static_cast<int>(static_cast<unsigned>(cy) < static_cast<unsigned>(th)))
+	{
+		const int p = cy * tw + cx;
+		if (U16)
+		{
+			atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
+		}
+		else
+		{
+			atomicAdd(&cnt[p], 1u);
+		}
+	}
+}
+
+// Unit waves over 2-D tiles (impl 5; the warped image of R2's final loop): workgroup = (tile,
+// window) with the tile's counters in LDS; the events are taken unit by unit, one wave per unit at
+// a time (an LDS work counter hands the units out), so a unit's reference-time offset and flow
+// are wave-uniform scalars; a tile only takes the units whose events can reach it: the unit's rect
+// grown by max|t_ref - t| x |scale| x |flow| (+1) on each axis.  Full-width row bands (impl 4) make
+// a large sensor's units visit 5-6 bands each (C4: 15-row bands against a reach of +-25 rows);
+// tiles a few hundred pixels on a side cut that to ~1.7 visits.  Tiles of a window take
+// consecutive slots of one XCD (blockIdx % 8) so that re-reads of a unit's events hit that L2.
+// One pass of a tile workgroup: rows [row0, row0 + th) x columns [x0, x0 + tw) counted in LDS from the
+// selected units (headers in hdr[0, nSel)), then stored.  U16: two 16-bit counters per dword.
+template <bool U16>
+__device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, const double* __restrict__ windowFlows,
+										   const int4* hdr, int nSel, int* ctl, unsigned int* cnt, int x0, int row0, int tw, int th,
+										   double* __restrict__ out /* image(row0, x0) */, int W, bool alignedImage,
+										   const EvalConsts& c)
+{
+	const int npx = tw * th;
+	const int nWords = U16 ? (npx + 1) >> 1 : npx;
+	for (int i = threadIdx.x; i < nWords; i += blockDim.x)
+	{
+		cnt[i] = 0u;
+	}
+	if (threadIdx.x == 0)
+	{
+		ctl[0] = 0;
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const float scalef = static_cast<float>(c.scale);
+	constexpr int kInFlight = 4;
+	// Software pipeline: the loads of the NEXT batch of 256 events (the same unit's, or the first
+	// of the next unit the wave picks) are in flight while the current batch is counted.
+	int4 hA = make_int4(0, 0, 0, 0);
+	uint32_t posA = 0;
+	bool haveA = false;
+	{
+		int pick = 0;
+		if (lane == 0)
+		{
+			pick = atomicAdd(&ctl[0], 1);
+		}
+		pick = __shfl(pick, 0, 64);
+		if (pick < nSel)
+		{
+			hA = hdr[pick];
+			posA = static_cast<uint32_t>(hA.x);
+			haveA = true;
+		}
+	}
+	uint64_t recsA[kInFlight];
+	if (haveA)
+	{
+#pragma unroll
+		for (int k = 0; k < kInFlight; ++k)
+		{
+			const uint32_t ek = posA + lane + k * 64;
+			recsA[k] = (ek < static_cast<uint32_t>(hA.y)) ? events[ek] : 0ull;
+		}
+	}
+	while (haveA)
+	{
+		// the batch after this one
+		int4 hB = hA;
+		uint32_t posB = posA + kInFlight * 64;
+		bool haveB = true;
+		if (posB >= static_cast<uint32_t>(hA.y))
+		{
+			int pick = 0;
+			if (lane == 0)
+			{
+				pick = atomicAdd(&ctl[0], 1);
+			}
+			pick = __shfl(pick, 0, 64);
+			haveB = pick < nSel;
+			if (haveB)
+			{
+				hB = hdr[pick];
+				posB = static_cast<uint32_t>(hB.x);
+			}
+		}
+		uint64_t recsB[kInFlight];
+		if (haveB)
+		{
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				const uint32_t ek = posB + lane + k * 64;
+				recsB[k] = (ek < static_cast<uint32_t>(hB.y)) ? events[ek] : 0ull;
+			}
+		}
+		// count batch A
+		{
+			const int u = hA.w;
+			const double m0 = windowFlows[2 * u], m1 = windowFlows[2 * u + 1];  // 16 KB per window: L1 / L2
+			const float m0f = static_cast<float>(m0), m1f = static_cast<float>(m1);
+#pragma unroll
+			for (int k = 0; k < kInFlight; ++k)
+			{
+				count_hit_uniform<U16>(recsA[k], posA + lane + k * 64 < static_cast<uint32_t>(hA.y), hA.z, m0, m1, m0f, m1f,
+									   scalef, c.scale, x0, row0, tw, th, cnt);
+			}
+		}
+		haveA = haveB;
+		hA = hB;
+		posA = posB;
+#pragma unroll
+		for (int k = 0; k < kInFlight; ++k)
+		{
+			recsA[k] = recsB[k];
+		}
+	}
+	__syncthreads();
+	if (U16 && !(tw & 1) && !(W & 1) && !(x0 & 1) && alignedImage)
+	{
+		// one packed dword = two pixels of one row = one 16-byte store
+		const int pairsPerRow = tw >> 1;
+		for (int i = threadIdx.x; i < (npx >> 1); i += blockDim.x)
+		{
+			const int r = i / pairsPerRow, q = i - r * pairsPerRow;
+			const unsigned int v = cnt[i];
+			*reinterpret_cast<double2*>(out + static_cast<size_t>(r) * W + 2 * q) =
+				make_double2(static_cast<double>(v & 0xFFFFu), static_cast<double>(v >> 16));
+		}
+	}
+	else
+	{
+		for (int p = threadIdx.x; p < npx; p += blockDim.x)
+		{
+			const int r = p / tw, q = p - r * tw;
+			const unsigned int v = U16 ? ((cnt[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu) : cnt[p];
+			out[static_cast<size_t>(r) * W + q] = static_cast<double>(v);
+		}
+	}
+	__syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) k_count_tiles(
+	const uint64_t* __restrict__ events, const Unit* __restrict__ units, const int32_t* __restrict__ unitMaxDt,
+	int unitsPerWindow, const double* __restrict__ flows, int tileW, int tileH, int tilesX, int tilesY, int cntBytes,
+	int nWindows, double* __restrict__ image, EvalConsts c)
+{
+	// tileW x tileH: the pitch of the tile grid (the last tile of a row / column takes what is left
+	// of the image); cntBytes: 2 bytes per pixel of a full tile
+	extern __shared__ unsigned int cnt[];
+	const int nTiles = tilesX * tilesY;
+	const int slot = blockIdx.x >> 3;
+	const int w = (slot / nTiles) * 8 + (blockIdx.x & 7);
+	if (w >= nWindows)
+	{
+		return;
+	}
+	const int tile = slot % nTiles;
+	const int tix = tile % tilesX, tiy = tile / tilesX;
+	const int x0 = tix * tileW, row0 = tiy * tileH;
+	const int tw = (tix == tilesX - 1) ? c.image_w - x0 : tileW, th = (tiy == tilesY - 1) ? c.image_h - row0 : tileH;
+	const int W = c.image_w;
+	const int P = c.npx * c.npy;
+	// behind the counters: [0] next, [1] nSel, [2] most events of a selected unit, [3] largest reach
+	// (ceil, both axes), then one 4-int header per selected unit {first event, end, dt_win, unit}: the
+	// waves walk the units from LDS, not through dependent global loads
+	int* ctl = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt) + cntBytes);
+	int4* hdr = reinterpret_cast<int4*>(ctl + 4);
+	if (threadIdx.x < 4)
+	{
+		ctl[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
+	const int32_t* wmax = unitMaxDt + static_cast<size_t>(w) * unitsPerWindow;
+	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
+	const double* windowFlows = flows + 2 * static_cast<size_t>(w) * P;
+	// which units can reach this tile (the stray unit is left to k_count_stray)
+	for (int u = threadIdx.x; u < P; u += blockDim.x)
+	{
+		const Unit un = wu[u];
+		bool take = un.n_ev > 0;
+		// |fl(fl(dtw * scale) * m)| <= fl(fl(maxdt * |scale|) * |m|): rounding is monotonic
+		const double t = static_cast<double>(wmax[u]) * fabs(c.scale);
+		const double reachX = t * fabs(windowFlows[2 * u]) + 1.0, reachY = t * fabs(windowFlows[2 * u + 1]) + 1.0;
+		if (take && nTiles > 1)
+		{
+			const double lox = static_cast<double>(un.rx) - reachX, hix = static_cast<double>(un.rx + un.rw - 1) + reachX;
+			const double loy = static_cast<double>(un.ry) - reachY, hiy = static_cast<double>(un.ry + un.rh - 1) + reachY;
+			// NaN / inf reach: comparisons false -> taken
+			take = !(hix < static_cast<double>(x0) - 0.5 || lox > static_cast<double>(x0 + tw) - 0.5 ||
+					 hiy < static_cast<double>(row0) - 0.5 || loy > static_cast<double>(row0 + th) - 0.5);
+		}
+		if (take)
+		{
+			hdr[atomicAdd(&ctl[1], 1)] = make_int4(static_cast<int>(un.ev_off), static_cast<int>(un.ev_off + un.n_ev), un.dt_win, u);
+			atomicMax(&ctl[2], static_cast<int>(min(un.n_ev, 0x7fffffffu)));
+			const double rr = fmax(reachX, reachY);
+			atomicMax(&ctl[3], (rr < 1e6) ? static_cast<int>(ceil(rr)) : 1000000);  // NaN -> 1000000
+		}
+	}
+	__syncthreads();
+	const int nSel = ctl[1];
+	// 16-bit counters are safe when no pixel can collect 65536 events: a pixel is within reach of at
+	// most (1 + 2 ceil(R / pw)) (1 + 2 ceil(R / ph)) patches (the grid's last patches are larger: fewer),
+	// each with at most ctl[2] events.  Otherwise (wild flows, one patch holding most of a window)
+	// the tile is counted in slices of half its rows with 32-bit counters: any input is handled, that one slowly.
+	const long nx = 1 + 2 * ((ctl[3] + c.patch_w - 1) / c.patch_w), ny = 1 + 2 * ((ctl[3] + c.patch_h - 1) / c.patch_h);
+	const bool safe16 = nx * ny * static_cast<long>(ctl[2]) < 65536;
+	double* out = image + static_cast<size_t>(w) * imgSize + static_cast<size_t>(row0) * W + x0;
+	const bool alignedImage = (reinterpret_cast<uintptr_t>(image) & 15) == 0;
+	if (safe16)
+	{
+		tile_pass<true>(events, windowFlows, hdr, nSel, ctl, cnt, x0, row0, tw, th, out, W, alignedImage, c);
+	}
+	else
+	{
+		// the LDS holds 2 bytes per pixel of a full tile: 32-bit counters for tileH / 2 rows at a time
+		const int hMax = max(tileH / 2, 1);
+		for (int r = 0; r < th; r += hMax)
+		{
+			tile_pass<false>(events, windowFlows, hdr, nSel, ctl, cnt, x0, row0 + r, tw, min(hMax, th - r),
+							 out + static_cast<size_t>(r) * W, W, alignedImage, c);
+		}
+	}
+}
+
+// The stray unit of every window (events outside the sensor; none in a real recording) for the
+// kernels that leave it out: warped by the flow of the clamped patch (:436-441), added with f64
+// atomics after the image has been stored.
+__global__ void k_count_stray(const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
+							  const double* __restrict__ flows, double* __restrict__ image, EvalConsts c)
+{
+	const int w = blockIdx.x;
+	const int P = c.npx * c.npy;
+	const Unit un = units[static_cast<size_t>(w) * unitsPerWindow + P];
+	const double* windowFlows = flows + 2 * static_cast<size_t>(w) * P;
+	double* img = image + static_cast<size_t>(w) * c.image_w * c.image_h;
+	for (uint32_t e = threadIdx.x; e < un.n_ev; e += blockDim.x)
+	{
+		const uint64_t rec = events[un.ev_off + e];
+		double m0, m1;
+		stray_flow(rec, windowFlows, c, m0, m1);
+		int nx, ny;
+		if (count_target<1>(rec, true, un.dt_win, m0, m1, nullptr, c, nx, ny))
+		{
+			unsafeAtomicAdd(&img[static_cast<size_t>(ny) * c.image_w + nx], 1.0);  // exact on integer counts
 		}
 	}
 }
@@ -2825,6 +3124,77 @@ int launch_count_image(const CountLaunch& L, void* stream)
 {
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	const size_t n = static_cast<size_t>(L.n_windows) * L.c.image_w * L.c.image_h;
+	// Unit waves over 2-D tiles (impl 5, k_count_tiles): the default for images warped by per-patch
+	// flows (mode 1) that do not fit one workgroup's counters, in launches with enough workgroups.
+	// Tile grid: the split (counters + unit headers <= 76 KB: two workgroups per CU, so that one's
+	// store phase overlaps the other's event phase) that minimises the expected number of tiles a
+	// unit visits.
+	if ((L.impl == 5 || (L.impl < 0 && L.mode == 1)) && L.mode == 1 && L.d_unit_maxdt && L.n_units_total > 0)
+	{
+		const int b = 2;  // 16-bit counters; a workgroup that cannot prove them safe counts its tile in two 32-bit halves
+		const int Pn = L.c.npx * L.c.npy;
+		const size_t ctlBytes = static_cast<size_t>(Pn + 1) * 16 + 16;  // one 16-byte header per unit the tile may select
+		const size_t budgetAll = static_cast<size_t>(L.lds_kb > 0 ? L.lds_kb : 76) * 1024;
+		const size_t budget = budgetAll > ctlBytes + 4096 ? budgetAll - ctlBytes : 4096;
+		const int W = L.c.image_w, H = L.c.image_h;
+		int bestX = 0, bestY = 0, bestW = 0, bestH = 0;
+		size_t bestBytes = 0;
+		double bestCost = 1e300;
+		// EQUAL tiles (balance beats alignment to the patch grid: whole-patch tiles with a larger last
+		// tile measured 3-4 points of HBM fraction worse at C3 and C4), even width (two 16-bit
+		// counters of a dword never straddle rows), cost = expected tiles a unit visits
+		const int pw = L.c.patch_w, ph = L.c.patch_h;
+		for (int tx = 1; tx <= 16 && ctlBytes <= 48 * 1024; ++tx)
+		{
+			int tw = (W + tx - 1) / tx;
+			tw += tw & 1;
+			if (tx > 1 && tw * (tx - 1) >= W)
+			{
+				continue;  // a coarser split covers the image with the same tile width
+			}
+			const int thMax = static_cast<int>(std::min<size_t>(budget / (static_cast<size_t>(tw) * b), static_cast<size_t>(H)));
+			if (thMax < 8)
+			{
+				continue;
+			}
+			const int ty = (H + thMax - 1) / thMax;
+			const int th = (H + ty - 1) / ty;
+			const double Rx = 0.5 * pw + 12.0, Ry = 0.5 * ph + 12.0;
+			const double cost = (tx > 1 ? (tw + 2 * Rx) / tw : 1.0) * (ty > 1 ? (th + 2 * Ry) / th : 1.0);
+			if (cost < bestCost - 1e-9)
+			{
+				bestCost = cost;
+				bestX = tx;
+				bestY = ty;
+				bestW = tw;
+				bestH = th;
+				bestBytes = (static_cast<size_t>(tw) * th * b + 15) & ~size_t(15);
+			}
+		}
+		const long wgs = static_cast<long>(L.n_windows) * bestX * bestY;
+		if (bestX > 0 && (L.impl == 5 || (bestX * bestY > 1 && wgs >= 64)))
+		{
+			auto kern = k_count_tiles;
+			const size_t lds = bestBytes + ctlBytes;
+			if (lds <= 160 * 1024 && allow_big_lds(kern, lds) == 0)
+			{
+				const int groups = (L.n_windows + 7) / 8;
+				hipLaunchKernelGGL(kern, dim3(groups * bestX * bestY * 8), dim3(1024), lds, s, L.d_events, L.d_units,
+								   L.d_unit_maxdt, L.units_per_window, static_cast<const double*>(L.d_aux), bestW, bestH, bestX,
+								   bestY, static_cast<int>(bestBytes), L.n_windows, L.d_image, L.c);
+				if (check_launch())
+				{
+					return -2;
+				}
+				if (L.any_stray)
+				{
+					hipLaunchKernelGGL(k_count_stray, dim3(L.n_windows), dim3(256), 0, s, L.d_events, L.d_units, L.units_per_window,
+									   static_cast<const double*>(L.d_aux), L.d_image, L.c);
+				}
+				return check_launch();
+			}
+		}
+	}
 	// Unit waves (impl 4, k_count_units): the default for images warped by per-patch flows that
 	// need SEVERAL bands, in launches with enough (band, window) workgroups -- C3 x 128 windows
 	// 0.179 -> 0.122 ms against impl 1, C4 x 32 0.311 -> 0.231 ms against impl 3; with one band

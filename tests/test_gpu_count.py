@@ -1,6 +1,8 @@
 """GPU tests of the count-image implementations (0: global int atomics, 1: whole-window LDS
 bands, 2: patch-row LDS bands with an overflow list for events that leave their band, 3: events
-sorted by destination band, 4: unit waves with a displacement bound per unit): all
+sorted by destination band, 4: unit waves with a displacement bound per unit, 5: unit waves over
+2-D tiles, 6: a rolling band per window that reads every event once, the default for warped images in
+large launches): all
 bit-exact against the oracle, on single windows and on batches, for all three modes."""
 import numpy as np
 import pytest
@@ -14,7 +16,7 @@ def _prm(orc, c):
                               patch_h=p.patch_h, scale=p.scale, min_events=p.min_events, loss=1)
 
 
-@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "auto"])
+@pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5", "auto"])
 @pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000), (4, 2, 60000)])
 def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config, n_windows, n_events):
     if impl == "auto":
@@ -47,7 +49,7 @@ def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config,
             assert np.array_equal(again[k], integ[k])
 
 
-@pytest.mark.parametrize("impl", ["1", "2"])
+@pytest.mark.parametrize("impl", ["1", "2", "5"])
 def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypatch, impl):
     """16-bit packed counters are only used below 65536 events per window."""
     monkeypatch.setenv("EBO_COUNT_IMPL", impl)
@@ -114,3 +116,39 @@ def test_patch_of_an_event_from_its_coordinates(ebo, orc, monkeypatch, impl, ima
         flows = rng.uniform(-1.5, 1.5, (c.P, 2))
         warped = c.count_image(ebo.COUNT_WARPED, flows)[0]
         assert np.array_equal(warped, orc.final_count_image(ev, prm, flows))
+
+
+@pytest.mark.parametrize("impl", ["5"])
+@pytest.mark.parametrize("w,h,pw,ph,n_events,lds_kb", [(347, 261, 21, 16, 30000, 16), (347, 261, 21, 16, 70000, 24),
+                                                      (64, 48, 7, 5, 4000, 1), (1280, 720, 40, 22, 200000, 0),
+                                                      (346, 260, 21, 16, 50000, 0), (240, 180, 30, 22, 20000, 40)])
+def test_tiled_count_image_odd_sizes_and_wide_counters(ebo, orc, synth, monkeypatch, impl, w, h, pw, ph, n_events, lds_kb):
+    """k_count_tiles (impl 5) and k_count_sweep (impl 6) on sizes that exercise their edges: odd image
+    widths (no 16-byte row stores, packed counters shared between rows), tiles / strips that do not
+    divide the image, 32-bit counters (>= 65536 events per window), tiny tiles and bands (every unit
+    reaches several; the rolling band falls back to band-by-band counting), flows large enough to
+    leave the image or NaN, stray events."""
+    monkeypatch.setenv("EBO_COUNT_IMPL", impl)
+    if lds_kb:
+        monkeypatch.setenv("EBO_COUNT_LDS_KB", str(lds_kb))
+    cfg = dict(name="t", image=(w, h), patch=(pw, ph), events=n_events, index=11)
+    n_windows = 3
+    ev, offsets, gt = synth.make_stream(cfg, n_windows)
+    ev["x"][3] = -5
+    ev["y"][7] = h + 2
+    ev["x"][11] = w + 40
+    with ebo.Context(image_w=w, image_h=h, patch_w=pw, patch_h=ph, loss=ebo.LOSS_VARIANCE, max_windows=n_windows,
+                     max_events=len(ev)) as c:
+        c.set_windows(ev, offsets)
+        prm = _prm(orc, c)
+        rng = np.random.RandomState(5)
+        flows = rng.uniform(-3, 3, (n_windows, c.P, 2))
+        flows[0, 0] = (40.0, -35.0)      # leaves the image
+        flows[1, 1] = (np.nan, 1.0)      # undefined in the reference: the event is skipped on both sides
+        warped = c.count_image(ebo.COUNT_WARPED, flows)
+        monkeypatch.setenv("EBO_COUNT_IMPL", "0")
+        plain = c.count_image(ebo.COUNT_WARPED, flows)
+        assert np.array_equal(warped, plain)
+        for k in range(n_windows):
+            sub = ev[int(offsets[k]):int(offsets[k + 1])]
+            assert np.array_equal(warped[k], orc.final_count_image(sub, prm, flows[k]))
