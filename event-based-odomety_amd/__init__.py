@@ -33,6 +33,9 @@ EVENT_DTYPE = np.dtype(
     [("x", "<i4"), ("y", "<i4"), ("sign", "<i4"), ("reserved", "<i4"), ("t_us", "<i8")]
 )
 
+# numpy mirror of ebo_event8 (compact raw event: x:15 | polarity:1 | y:15 | 0:1, int32 us relative to a base time)
+EVENT8_DTYPE = np.dtype([("xy", "<u4"), ("t_rel_us", "<i4")])
+
 # numpy mirror of ebo_track_point (one "feature_id timestamp x y" record, 32 bytes)
 TRACK_DTYPE = np.dtype([("id", "<i8"), ("t_us", "<i8"), ("x", "<f8"), ("y", "<f8")])
 
@@ -246,6 +249,17 @@ def read_tracks_txt(path, cap=1 << 20):
     return out[: n.value].copy()
 
 
+def pack_events8(ev, t_base, out=None):
+    """EventSamples of one window -> compact 8-byte records relative to t_base."""
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    if out is None:
+        out = np.zeros(len(ev), dtype=EVENT8_DTYPE)
+    rc = lib().ebo_pack_events8(_vp(ev), C.c_size_t(len(ev)), C.c_int64(int(t_base)), _vp(out))
+    if rc:
+        raise EboError(rc, "event does not fit the compact record")
+    return out
+
+
 def make_events(x, y, t_us, sign=None):
     ev = np.zeros(len(x), dtype=EVENT_DTYPE)
     ev["x"] = x
@@ -322,6 +336,24 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         self._check(lib().ebo_set_windows_device(self._h, C.c_void_p(int(d_events)), _vp(offsets), int(n)))
+        self.n_windows = n
+        self._custom = None
+
+    def set_windows8(self, ev8, t_base, offsets, device=False):
+        """Compact 8-byte records (EVENT8_DTYPE array or, with device=True, a device pointer)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        t_base = np.ascontiguousarray(t_base, dtype=np.int64)
+        n = len(offsets) - 1
+        assert len(t_base) == n
+        if device:
+            self._check(lib().ebo_set_windows8_device(self._h, C.c_void_p(int(ev8)), _vp(t_base), _vp(offsets), int(n)))
+        else:
+            if isinstance(ev8, np.ndarray):
+                ev8 = np.ascontiguousarray(ev8, dtype=EVENT8_DTYPE)
+                ptr = _vp(ev8)
+            else:
+                ptr = C.c_void_p(int(ev8))  # e.g. the address of page-locked memory
+            self._check(lib().ebo_set_windows8(self._h, ptr, _vp(t_base), _vp(offsets), int(n)))
         self.n_windows = n
         self._custom = None
 

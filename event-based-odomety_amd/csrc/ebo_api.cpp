@@ -1494,6 +1494,20 @@ int ebo_create(const ebo_params* p, ebo_ctx** out)
 
 void ebo_destroy(ebo_ctx* c)
 {
+	if (c && c->copy_stream)
+	{
+		(void)hipSetDevice(c->prm.device);
+		(void)hipStreamSynchronize(c->copy_stream);
+		for (hipEvent_t& e : c->copy_done)
+		{
+			if (e)
+			{
+				(void)hipEventDestroy(e);
+			}
+		}
+		(void)hipStreamDestroy(c->copy_stream);
+		c->copy_stream = nullptr;
+	}
 	if (!c)
 	{
 		return;

@@ -96,7 +96,9 @@ struct ebo_ctx
 	size_t tvf_cap = 0;
 	void* comm = nullptr;            // ncclComm_t of ebo_comm_init
 	int comm_rank = 0, comm_size = 1;
-	void* d_raw = nullptr;           // raw 24-byte events staged for device bucketing
+	void* d_raw = nullptr;           // raw 24-byte (or compact 8-byte) events staged for device bucketing
+	hipStream_t copy_stream = nullptr;  // uploads of ebo_set_windows / ebo_set_windows8, overlapped with the bucketing
+	hipEvent_t copy_done[8] = {};
 	void* d_bucket = nullptr;        // bucketing scratch
 	size_t bucket_cap = 0;
 

@@ -184,7 +184,10 @@ int launch_count_image(const CountLaunch& L, void* stream);
 // Device-side bucketing of raw 24-byte events (ebo_bucket.inc).
 struct BucketLaunch
 {
-	const void* d_raw;                 // ebo_event[] on the device
+	const void* d_raw;                 // ebo_event[] (24 B) or ebo_event8[] (8 B) on the device
+	int compact = 0;                   // 1: d_raw holds ebo_event8 records, times relative to d_tbase[window]
+	const long long* d_tbase = nullptr; // [n_windows] base times of the compact records
+	int w0 = 0, w1 = -1;               // window range of this call ([0, n_windows) when w1 < 0); init runs with w0 == 0
 	const unsigned long long* d_offsets; // [n_windows + 1], absolute indices into d_raw
 	int n_windows;
 	int P;

@@ -2990,32 +2990,40 @@ int launch_optimizer_interleave(const double* d_gx, const double* d_gy, size_t n
 	return check_launch();
 }
 
-int launch_bucket(const BucketLaunch& L, void* stream)
+template <class Rec>
+static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 {
-	hipStream_t s = static_cast<hipStream_t>(stream);
 	const int nUnits = L.n_windows * (L.P + 1);
-	const RawEvent* raw = static_cast<const RawEvent*>(L.d_raw);
-	hipLaunchKernelGGL(k_bucket_init, dim3((nUnits + 255) / 256), dim3(256), 0, s, L.d_cnt, L.d_tmin,
-					   L.d_tmax, nUnits, L.d_flag);
-	if (check_launch())
+	const int w0 = L.w0, w1 = L.w1 < 0 ? L.n_windows : L.w1;
+	const int nw = w1 - w0;
+	if (w0 == 0)
 	{
-		return -2;
-	}
-	const size_t lds = static_cast<size_t>(L.P + 1) * (2 * sizeof(long long) + sizeof(int)) + 8;
-	if (L.max_chunks > 0)
-	{
-		if (allow_big_lds(k_bucket_count, lds))
-		{
-			return -2;
-		}
-		hipLaunchKernelGGL(k_bucket_count, dim3(L.max_chunks, L.n_windows), dim3(256), lds, s, raw,
-						   L.d_offsets, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.c);
+		hipLaunchKernelGGL(k_bucket_init, dim3((nUnits + 255) / 256), dim3(256), 0, s, L.d_cnt, L.d_tmin,
+						   L.d_tmax, nUnits, L.d_flag);
 		if (check_launch())
 		{
 			return -2;
 		}
 	}
-	hipLaunchKernelGGL(k_bucket_scan, dim3(L.n_windows), dim3(256), 0, s, raw, L.d_offsets,
+	if (nw <= 0)
+	{
+		return 0;
+	}
+	const size_t lds = static_cast<size_t>(L.P + 1) * (2 * sizeof(long long) + sizeof(int)) + 8;
+	if (L.max_chunks > 0)
+	{
+		if (allow_big_lds(k_bucket_count<Rec>, lds))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(k_bucket_count<Rec>, dim3(L.max_chunks, nw), dim3(256), lds, s, raw,
+						   L.d_offsets, w0, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.c);
+		if (check_launch())
+		{
+			return -2;
+		}
+	}
+	hipLaunchKernelGGL(k_bucket_scan<Rec>, dim3(nw), dim3(256), 0, s, raw, L.d_offsets, w0,
 					   L.n_windows, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.min_events, L.d_units,
 					   L.d_unit_tref, L.d_unit_maxdt, L.d_win_tref, L.d_flag, L.c);
 	if (check_launch())
@@ -3024,8 +3032,8 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 	}
 	if (L.max_chunks > 0)
 	{
-		hipLaunchKernelGGL(k_bucket_scatter, dim3(L.max_chunks, L.n_windows), dim3(256), 0, s, raw,
-						   L.d_offsets, L.P, L.d_cnt, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
+		hipLaunchKernelGGL(k_bucket_scatter<Rec>, dim3(L.max_chunks, nw), dim3(256), 0, s, raw,
+						   L.d_offsets, w0, L.P, L.d_cnt, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
 						   L.d_flag, L.c);
 		if (check_launch())
 		{
@@ -3036,9 +3044,25 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 		{
 			return -2;
 		}
-		hipLaunchKernelGGL(k_bucket_sort, dim3(nUnits), dim3(256), sortLds, s, L.d_units, L.d_packed);
+		hipLaunchKernelGGL(k_bucket_sort, dim3(nw * (L.P + 1)), dim3(256), sortLds, s,
+						   L.d_units + static_cast<size_t>(w0) * (L.P + 1), L.d_packed);
 	}
 	return check_launch();
+}
+
+int launch_bucket(const BucketLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (L.compact)
+	{
+		Rec8 r;
+		r.p = static_cast<const uint2*>(L.d_raw);
+		r.tbase = L.d_tbase;
+		return launch_bucket_t(L, r, s);
+	}
+	Rec24 r;
+	r.p = static_cast<const RawEvent*>(L.d_raw);
+	return launch_bucket_t(L, r, s);
 }
 
 int launch_eval_edge(const EdgeLaunch& L, void* stream)

@@ -9,7 +9,12 @@ extern "C" {
 
 // Bucketing + packing on the device (ebo_bucket.inc).  d_raw: ebo_event[] on the device,
 // offsets: host, absolute indices into d_raw.
-static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* offsets, int n_windows)
+// h_src != nullptr: the records are still on the host; they are uploaded in a few groups of
+// windows on a second stream while the groups before them are bucketed (the upload is most of
+// the set-up time: PCIe moves ~50 GB/s from page-locked memory, the bucketing kernels 6-10 G events/s).
+// compact: 8-byte ebo_event8 records with per-window base times (host array t_base).
+static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* offsets, int n_windows, int compact = 0,
+								 const int64_t* t_base = nullptr, const void* h_src = nullptr)
 {
 	const size_t total = offsets[n_windows] - offsets[0];
 	const int P = c->P;
@@ -29,10 +34,10 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 		}
 	}
 	(void)hipSetDevice(c->prm.device);
-	// one scratch block: offsets | cnt | tmin | tmax | unit tref | window tref | flag
+	// one scratch block: offsets | cnt | tmin | tmax | unit tref | window tref | flag | base times
 	auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
 	const size_t bOff = al((n_windows + 1) * 8), bCnt = al(nUnits * 4), bT = al(nUnits * 8), bW = al(n_windows * 8);
-	const size_t need = bOff + bCnt + 3 * bT + bW + 256;
+	const size_t need = bOff + bCnt + 3 * bT + bW + 256 + bW;
 	if (need > c->bucket_cap)
 	{
 		if (c->d_bucket)
@@ -58,6 +63,8 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	L.d_unit_tref = reinterpret_cast<long long*>(base + bOff + bCnt + 2 * bT);
 	L.d_win_tref = reinterpret_cast<long long*>(base + bOff + bCnt + 3 * bT);
 	L.d_flag = reinterpret_cast<int*>(base + bOff + bCnt + 3 * bT + bW);
+	L.compact = compact;
+	L.d_tbase = reinterpret_cast<long long*>(base + bOff + bCnt + 3 * bT + bW + 256);
 	L.n_windows = n_windows;
 	L.P = P;
 	L.max_chunks = static_cast<int>((maxWin + 2047) / 2048);
@@ -71,7 +78,7 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	// staged one by one by the runtime: 0.176 -> 0.131 ms for a 15 k-event window)
 	const size_t tail = bT + bW + 256;  // unit tref | window tref | flag, contiguous in the scratch block
 	const size_t pUnits = al(nUnits * sizeof(Unit));
-	const size_t pinNeed = bOff + pUnits + tail;
+	const size_t pinNeed = bOff + pUnits + tail + bW;
 	if (pinNeed > c->pin_bucket_cap)
 	{
 		if (c->pin_bucket)
@@ -96,9 +103,83 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	{
 		return rc;
 	}
-	if (launch_bucket(L, c->stream))
+	if (compact)
 	{
-		return c->hip(hipGetLastError(), "bucket launch");
+		char* pinBase = pin + bOff + pUnits + tail;
+		std::memcpy(pinBase, t_base, static_cast<size_t>(n_windows) * 8);
+		rc = c->hip(hipMemcpyAsync(const_cast<long long*>(L.d_tbase), pinBase, static_cast<size_t>(n_windows) * 8,
+								   hipMemcpyHostToDevice, c->stream),
+					"H2D base times");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	const size_t recBytes = compact ? 8 : sizeof(ebo_event);
+	if (!h_src || total == 0)
+	{
+		if (launch_bucket(L, c->stream))
+		{
+			return c->hip(hipGetLastError(), "bucket launch");
+		}
+	}
+	else
+	{
+		// groups of whole windows, each at least ~8 MB, at most 8 groups
+		if (!c->copy_stream)
+		{
+			rc = c->hip(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "copy stream");
+			for (int g = 0; g < 8 && rc == EBO_OK; ++g)
+			{
+				rc = c->hip(hipEventCreateWithFlags(&c->copy_done[g], hipEventDisableTiming), "copy event");
+			}
+			if (rc)
+			{
+				return rc;
+			}
+		}
+		const size_t perGroup = std::max<size_t>((total * recBytes + 7) / 8, static_cast<size_t>(8) << 20);
+		int w0 = 0, g = 0;
+		// the upload may not overtake earlier work of the context's stream that still reads d_raw
+		hipError_t he = hipEventRecord(c->copy_done[7], c->stream);
+		if (he == hipSuccess) he = hipStreamWaitEvent(c->copy_stream, c->copy_done[7], 0);
+		while (w0 < n_windows && he == hipSuccess)
+		{
+			int w1 = w0 + 1;
+			while (w1 < n_windows && (g == 6 ? false : (offsets[w1] - offsets[w0]) * recBytes < perGroup))
+			{
+				++w1;
+			}
+			if (g == 6)
+			{
+				w1 = n_windows;  // the last group takes the rest
+			}
+			const size_t b0 = (offsets[w0] - offsets[0]) * recBytes, b1 = (offsets[w1] - offsets[0]) * recBytes;
+			if (b1 > b0)
+			{
+				he = hipMemcpyAsync(static_cast<char*>(const_cast<void*>(d_raw)) + b0, static_cast<const char*>(h_src) + b0, b1 - b0,
+									hipMemcpyHostToDevice, c->copy_stream);
+			}
+			if (he == hipSuccess) he = hipEventRecord(c->copy_done[g], c->copy_stream);
+			if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, c->copy_done[g], 0);
+			if (he != hipSuccess)
+			{
+				break;
+			}
+			L.w0 = w0;
+			L.w1 = w1;
+			if (launch_bucket(L, c->stream))
+			{
+				return c->hip(hipGetLastError(), "bucket launch");
+			}
+			w0 = w1;
+			++g;
+		}
+		if (he != hipSuccess)
+		{
+			c->n_windows = 0;
+			return c->hip(he, "pipelined upload");
+		}
 	}
 	hipError_t e = hipMemcpyAsync(pin + bOff, c->d_units, nUnits * sizeof(Unit), hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(pin + bOff + pUnits, L.d_unit_tref, tail, hipMemcpyDeviceToHost, c->stream);
@@ -212,22 +293,99 @@ int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int 
 			return rc;
 		}
 	}
-	if (total > 0)
-	{
-		int rc = c->hip(hipMemcpyAsync(c->d_raw, ev + offsets[0], total * sizeof(ebo_event),
-									   hipMemcpyHostToDevice, c->stream),
-						"H2D raw events");
-		if (rc)
-		{
-			return rc;
-		}
-	}
 	std::vector<size_t> rel(n_windows + 1);
 	for (int w = 0; w <= n_windows; ++w)
 	{
 		rel[w] = offsets[w] - offsets[0];
 	}
-	return set_windows_on_device(c, c->d_raw, rel.data(), n_windows);
+	return set_windows_on_device(c, c->d_raw, rel.data(), n_windows, 0, nullptr, total > 0 ? ev + offsets[0] : nullptr);
+}
+
+// ---- compact 8-byte input (ebo_event8) -----------------------------------------------------
+int ebo_pack_events8(const ebo_event* ev, size_t n, int64_t t_base, ebo_event8* out)
+{
+	if ((n && !ev) || (n && !out))
+	{
+		return EBO_ERR_ARG;
+	}
+	for (size_t i = 0; i < n; ++i)
+	{
+		const int64_t dt = ev[i].t_us - t_base;
+		if (ev[i].x < kCoordMin || ev[i].x > kCoordMax || ev[i].y < kCoordMin || ev[i].y > kCoordMax ||
+			dt < INT32_MIN || dt > INT32_MAX)
+		{
+			return EBO_ERR_RANGE;
+		}
+		out[i].xy = pack_lo(ev[i].x, ev[i].y, ev[i].sign > 0);
+		out[i].t_rel_us = static_cast<int32_t>(dt);
+	}
+	return EBO_OK;
+}
+
+static int check_windows8(ebo_ctx* c, const void* ev, const int64_t* t_base, const size_t* offsets, int n_windows)
+{
+	if (!offsets || !t_base || n_windows <= 0 || (!ev && offsets[n_windows] > offsets[0]))
+	{
+		return c->fail(EBO_ERR_ARG, "null events/base times/offsets or no window");
+	}
+	if (n_windows > c->cap_windows)
+	{
+		return c->fail(EBO_ERR_ARG, "more windows than max_windows");
+	}
+	if (offsets[n_windows] - offsets[0] > c->cap_events)
+	{
+		return c->fail(EBO_ERR_ARG, "more events than max_events");
+	}
+	if (!device_bucketing_fits(c))
+	{
+		return c->fail(EBO_ERR_UNSUPPORTED,
+					   "device bucketing keeps one histogram slot per patch in LDS (about 8000 patches); "
+					   "pass 24-byte host events to ebo_set_windows for finer grids");
+	}
+	return EBO_OK;
+}
+
+int ebo_set_windows8_device(ebo_ctx* c, const ebo_event8* d_ev, const int64_t* t_base, const size_t* offsets, int n_windows)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	int rc = check_windows8(c, d_ev, t_base, offsets, n_windows);
+	if (rc)
+	{
+		return rc;
+	}
+	return set_windows_on_device(c, d_ev, offsets, n_windows, 1, t_base, nullptr);
+}
+
+int ebo_set_windows8(ebo_ctx* c, const ebo_event8* ev, const int64_t* t_base, const size_t* offsets, int n_windows)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	int rc = check_windows8(c, ev, t_base, offsets, n_windows);
+	if (rc)
+	{
+		return rc;
+	}
+	(void)hipSetDevice(c->prm.device);
+	if (!c->d_raw)
+	{
+		rc = c->hip(hipMalloc(&c->d_raw, c->cap_events * sizeof(ebo_event)), "hipMalloc raw events");
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	const size_t total = offsets[n_windows] - offsets[0];
+	std::vector<size_t> rel(n_windows + 1);
+	for (int w = 0; w <= n_windows; ++w)
+	{
+		rel[w] = offsets[w] - offsets[0];
+	}
+	return set_windows_on_device(c, c->d_raw, rel.data(), n_windows, 1, t_base, total > 0 ? ev + offsets[0] : nullptr);
 }
 
 static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int n_windows)

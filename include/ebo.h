@@ -165,6 +165,25 @@ int ebo_set_windows(ebo_ctx* ctx, const ebo_event* ev, const size_t* offsets, in
  * uses this path after one H2D copy of the raw events (EBO_BUCKET=host selects the host
  * counting sort instead). */
 int ebo_set_windows_device(ebo_ctx* ctx, const ebo_event* d_ev, const size_t* offsets, int n_windows);
+/* Compact raw event, 8 bytes -- a third of what common::EventSample moves over PCIe, which is most
+ * of a window's set-up time: xy = x:15 | polarity:1 | y:15 | 0:1 (coordinates two's complement in
+ * [-16384, 16383]; polarity 1 = +1), t_rel_us = t - t_base[window] in microseconds.  The packed
+ * sidecar of a recording or a sensor driver can produce it directly; ebo_pack_events8 converts a
+ * window of EventSamples (EBO_ERR_RANGE for a coordinate or a time that does not fit). */
+typedef struct ebo_event8
+{
+	uint32_t xy;
+	int32_t t_rel_us;
+} ebo_event8;
+int ebo_pack_events8(const ebo_event* ev, size_t n, int64_t t_base, ebo_event8* out);
+/* ebo_set_windows on compact records: window w = ev[offsets[w] .. offsets[w+1]) with base time
+ * t_base[w] (host arrays).  ev is host memory (page-locked memory -- hipHostMalloc /
+ * hipHostRegister -- reaches the PCIe rate; the upload runs in groups of windows overlapped with
+ * the bucketing of the groups before), or device memory for the _device form.  Results are
+ * identical to ebo_set_windows on the same events. */
+int ebo_set_windows8(ebo_ctx* ctx, const ebo_event8* ev, const int64_t* t_base, const size_t* offsets, int n_windows);
+int ebo_set_windows8_device(ebo_ctx* ctx, const ebo_event8* d_ev, const int64_t* t_base, const size_t* offsets,
+							int n_windows);
 /* Arbitrary patches instead of a window: patch i = cv::Rect2i rects[i][4] = (x,y,w,h)
  * with its own event list ev[offsets[i]..offsets[i+1]) in list order, exactly what
  * tracker::contrastFunctor's constructor takes (contrast_functor.h:12-21; events

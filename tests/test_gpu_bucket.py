@@ -98,3 +98,53 @@ def test_device_bucketing_error_flags(ebo, synth):
         assert ei.value.code == ebo.ERR_RANGE and "int32" in str(ei.value)
         c.set_window(ev)
         assert c.eval(np.zeros((c.P, 2)))[0].shape == (1, c.P)
+
+
+@pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 9, 20000), (3, 20, 120000), (4, 3, 150000)])
+def test_compact_records_give_the_same_windows(ebo, synth, config, n_windows, n_events):
+    """ebo_set_windows8 (8-byte records, per-window base times, upload pipelined with the bucketing in
+    groups of windows) against ebo_set_windows (24-byte EventSamples) on the same events: the same
+    unit tables, reference times, objective values, Jacobians and count images, bit for bit; from
+    host memory and from device memory; with strays; with a base time that is not the first event's."""
+    import torch
+    ev, offsets, gt = synth.make_stream(config, n_windows, n_events=n_events)
+    ev["x"][3] = -2  # strays
+    ev["y"][11] = 15000
+    t_base = np.array([int(ev["t_us"][int(offsets[w])]) - 7 * w for w in range(n_windows)], dtype=np.int64)
+    ev8 = np.concatenate([ebo.pack_events8(ev[int(offsets[w]):int(offsets[w + 1])], t_base[w]) for w in range(n_windows)])
+    assert ev8.dtype.itemsize == 8 and len(ev8) == len(ev)
+
+    def snapshot(c):
+        info = [[c.patch_info(p, w) for p in range(c.P)] for w in range(n_windows)]
+        wins = [c.window_info(w) for w in range(n_windows)]
+        r, J = c.eval(gt * 0.5)
+        return info, wins, r, J, c.count_image(ebo.COUNT_WARPED, gt * 0.7), c.count_image(ebo.COUNT_INTEGRATED)
+
+    with build(ebo, synth, config, ev, offsets) as c:
+        c.set_windows(ev, offsets)
+        ref = snapshot(c)
+        c.set_windows8(ev8, t_base, offsets)
+        a = snapshot(c)
+        d8 = torch.from_numpy(ev8.view(np.uint8).reshape(-1, 8)).to("cuda")
+        c.set_windows8(d8.data_ptr(), t_base, offsets, device=True)
+        b = snapshot(c)
+        pinned = torch.from_numpy(ev8.view(np.uint8).reshape(-1, 8)).pin_memory()
+        c.set_windows8(pinned.data_ptr(), t_base, offsets)
+        p = snapshot(c)
+    for got in (a, b, p):
+        assert got[0] == ref[0] and got[1] == ref[1]
+        for k in range(2, 6):
+            assert np.array_equal(got[k], ref[k])
+
+
+def test_compact_record_range_errors(ebo):
+    ev = ebo.make_events([1, 2], [3, 4], [10, 5_000_000_000])
+    with pytest.raises(ebo.EboError) as ei:
+        ebo.pack_events8(ev, 0)  # 5e9 us does not fit int32
+    assert ei.value.code == ebo.ERR_RANGE
+    ev = ebo.make_events([1, 20000], [3, 4], [10, 20])
+    with pytest.raises(ebo.EboError):
+        ebo.pack_events8(ev, 0)  # x beyond 15 bits
+    ok = ebo.pack_events8(ebo.make_events([-3, 5], [7, -1], [100, 90], sign=[1, -1]), 95)
+    assert ok["t_rel_us"].tolist() == [5, -5]
+    assert (ok["xy"] & 0x7FFF).tolist() == [(-3) & 0x7FFF, 5] and ((ok["xy"] >> 15) & 1).tolist() == [1, 0]
