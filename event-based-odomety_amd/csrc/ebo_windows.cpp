@@ -644,6 +644,14 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 				static_cast<uint64_t>(pack_lo(pe[i].x, pe[i].y, pe[i].sign > 0)) |
 				(static_cast<uint64_t>(static_cast<uint32_t>(static_cast<int32_t>(dt))) << 32);
 		}
+		// the canonical order of a unit (ascending packed record; units above 8192 events stay in
+		// list order), as the window paths leave it: a patch loaded here evaluates to the same bits as
+		// the same patch inside a window
+		if (n >= 2 && n <= 8192)
+		{
+			std::sort(c->h_packed.begin() + static_cast<std::ptrdiff_t>(base),
+					  c->h_packed.begin() + static_cast<std::ptrdiff_t>(base + n));
+		}
 		base += n;
 	}
 	(void)hipSetDevice(c->prm.device);

@@ -1,0 +1,210 @@
+// ceres_adaptor_test.cpp — the Ceres surface of the drop-in boundary, compiled and run.
+//
+// tracker::HipContrastCost (a ceres::SizedCostFunction<1, 2>) and tracker::ContrastBatch (a
+// ceres::EvaluationCallback) replace `new ceres::AutoDiffCostFunction<contrastFunctor, 1, 2>(new
+// contrastFunctor(patchEvents, patchRect, compensateScale))` of the reference
+// (feature_detector.cpp:359-363).  This program builds the problem of
+// FeatureDetector::compensateEventsContrast exactly as the reference does -- grid, per-patch
+// event lists by cv::Rect::contains, a data block iff the patch holds more than
+// compensateMinNumEvents events, parameter array mf = 0 (feature_detector.cpp:301-367) -- against
+// the test-only declarations of tests/cpp/stubs/ceres/ceres.h, and minimises it with the product's
+// own trust-region LM (csrc/host_lm.cpp, which carries the TV blocks of :369-396 itself) in place
+// of ceres::Solve: every evaluation goes PrepareForEvaluation -> CostFunction::Evaluate per block,
+// the way Ceres calls them.  The flows must equal ebo_solve(EBO_SOLVE_GLOBAL) of the same window.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <vector>
+
+#include "../../event-based-odomety_amd/include/feature_tracker/contrast_functor.h"
+#include "../../event-based-odomety_amd/csrc/host_lm.h"
+
+#ifndef EBO_HAVE_CERES
+#error "build with -Itests/cpp/stubs: the point of this test is the EBO_HAVE_CERES branch"
+#endif
+
+static int failures = 0;
+#define EXPECT_TRUE(c)                                                    \
+	do                                                                    \
+	{                                                                     \
+		if (!(c))                                                         \
+		{                                                                 \
+			std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c);    \
+			++failures;                                                   \
+		}                                                                 \
+	} while (0)
+
+static std::vector<common::EventSample> makeEvents(int n, uint64_t seed)
+{
+	// edges moving at a per-region flow + noise, as the bench's generator does, in plain C++
+	std::vector<common::EventSample> out;
+	uint64_t s = seed;
+	auto rnd = [&]() {
+		s += 0x9E3779B97F4A7C15ull;
+		uint64_t z = s;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	};
+	auto unit = [&]() { return static_cast<double>(rnd() >> 11) * (1.0 / 9007199254740992.0); };
+	for (int i = 0; i < n; ++i)
+	{
+		const int64_t t = 1000000 + static_cast<int64_t>(50000.0 * i / n);
+		const int px = static_cast<int>(unit() * 12), py = static_cast<int>(unit() * 9);
+		const double vx = ((px * 7 + py * 3) % 11) / 5.5 - 1.0, vy = ((px * 5 + py * 9) % 13) / 6.5 - 1.0;
+		const double dt = (static_cast<double>(t) - 1025000.0) * 1e-3;
+		double x = px * 20 + 10 + (unit() * 2 - 1) * 6 * ((px + py) % 2 ? 1.0 : 0.2) + vx * dt + std::floor(unit() * 3) - 1;
+		double y = py * 20 + 10 + (unit() * 2 - 1) * 6 * ((px + py) % 2 ? 0.2 : 1.0) + vy * dt + std::floor(unit() * 3) - 1;
+		common::EventSample e;
+		e.value.point = {static_cast<int>(std::fmin(std::fmax(std::floor(x), 0), 239)),
+						 static_cast<int>(std::fmin(std::fmax(std::floor(y), 0), 179))};
+		e.value.sign = (rnd() & 1) ? common::EventPolarity::POSITIVE : common::EventPolarity::NEGATIVE;
+		e.timestamp = common::timestamp_t(t);
+		out.push_back(e);
+	}
+	return out;
+}
+
+// ceres::Solve's role: the product's host LM over the stub Problem's blocks
+static ebo::HostLm::Stats solveThroughCeresSurface(ceres::Problem& problem, int npx, int npy,
+												   const std::vector<int>& patchOfBlock, double* mf, double tvWeight,
+												   double tvHuber, const ebo_solver_opts& opts)
+{
+	const int P = npx * npy;
+	std::vector<uint8_t> active(P, 0);
+	for (int p : patchOfBlock)
+	{
+		active[p] = 1;
+	}
+	ebo::HostLm lm(npx, npy, active, tvWeight, tvHuber, opts);
+	std::vector<double> x(2 * P), r(P), J(2 * P);
+	ceres::EvaluationCallback* callback = problem.options().evaluation_callback;
+	for (;;)
+	{
+		const ebo::HostLm::Request req = lm.request(x.data());
+		if (req == ebo::HostLm::DONE)
+		{
+			break;
+		}
+		std::memcpy(mf, x.data(), sizeof(double) * 2 * P);  // Ceres writes the parameter blocks in place
+		const bool wantJ = req == ebo::HostLm::NEED_JACOBIAN;
+		callback->PrepareForEvaluation(wantJ, true);
+		std::fill(r.begin(), r.end(), 0.0);
+		std::fill(J.begin(), J.end(), 0.0);
+		for (size_t b = 0; b < problem.blocks().size(); ++b)
+		{
+			const ceres::Problem::Block& blk = problem.blocks()[b];
+			const int p = patchOfBlock[b];
+			double const* params[1] = {blk.x};
+			double res[1];
+			double jac[2];
+			double* jacs[1] = {jac};
+			EXPECT_TRUE(blk.cost->num_residuals() == 1 && blk.cost->parameter_block_sizes().size() == 1 &&
+						blk.cost->parameter_block_sizes()[0] == 2);
+			const bool ok = blk.cost->Evaluate(params, res, wantJ ? jacs : nullptr);
+			EXPECT_TRUE(ok);
+			r[p] = res[0];
+			if (wantJ)
+			{
+				J[2 * p] = jac[0];
+				J[2 * p + 1] = jac[1];
+			}
+		}
+		lm.supply(r.data(), wantJ ? J.data() : nullptr);
+	}
+	lm.result(x.data());
+	std::memcpy(mf, x.data(), sizeof(double) * 2 * P);
+	return lm.stats();
+}
+
+static void runCase(int loss, const char* name)
+{
+	const tracker::DetectorParams dp;  // reference defaults: 240x180, 20x20, TV 1e3, Huber 10, scale 1e-3, > 100 events
+	const std::vector<common::EventSample> samples = makeEvents(15000, 20200701);
+	const std::list<common::EventSample> events(samples.begin(), samples.end());
+
+	// feature_detector.cpp:301-346: the grid
+	const int pw = dp.patchCompensateSize.width, ph = dp.patchCompensateSize.height;
+	const int npx = dp.imageSize.width / pw, npy = dp.imageSize.height / ph;
+	const int P = npx * npy;
+	std::vector<double> mf(2 * static_cast<size_t>(P), 0.0);  // :318-326
+
+	tracker::ContrastBatch batch(dp.compensateScale, loss);
+	ceres::Problem::Options options;
+	options.evaluation_callback = &batch;
+	ceres::Problem problem(options);
+	std::vector<int> patchOfBlock;
+	for (int y = 0; y < npy; ++y)
+	{
+		for (int x = 0; x < npx; ++x)
+		{
+			tracker::Rect2i rect(x * pw, y * ph, x == npx - 1 ? dp.imageSize.width - x * pw : pw,
+								 y == npy - 1 ? dp.imageSize.height - y * ph : ph);
+			std::list<common::EventSample> patchEvents;  // :348-355
+			for (const auto& e : events)
+			{
+				if (rect.contains(e.value.point))
+				{
+					patchEvents.push_back(e);
+				}
+			}
+			if (patchEvents.size() > dp.compensateMinNumEvents)  // :357
+			{
+				const int p = y * npx + x;
+				const int index = batch.addPatch(patchEvents, rect, &mf[2 * p]);
+				problem.AddResidualBlock(new tracker::HipContrastCost(&batch, index), nullptr, &mf[2 * p]);
+				patchOfBlock.push_back(p);
+			}
+		}
+	}
+	EXPECT_TRUE(problem.NumResidualBlocks() > 50);
+
+	ebo_solver_opts opts;
+	ebo_default_solver(&opts);  // :401-410
+	const ebo::HostLm::Stats st = solveThroughCeresSurface(problem, npx, npy, patchOfBlock, mf.data(), dp.compensateTVweight,
+														   dp.compensateTVHuberLoss, opts);
+
+	// the same window through the C ABI's own global solve
+	ebo_params prm;
+	ebo_default_params(&prm);
+	prm.loss = loss;
+	prm.max_events = samples.size();
+	ebo_ctx* ctx = nullptr;
+	EXPECT_TRUE(ebo_create(&prm, &ctx) == EBO_OK);
+	const std::vector<ebo_event> ev = common::toEboEvents(events);
+	EXPECT_TRUE(ebo_set_window(ctx, ev.data(), ev.size()) == EBO_OK);
+	std::vector<double> ref(2 * static_cast<size_t>(P), 0.0);
+	ebo_summary sum;
+	EXPECT_TRUE(ebo_solve(ctx, &opts, ref.data(), &sum) == EBO_OK);
+	ebo_destroy(ctx);
+
+	double maxd = 0.0;
+	int differing = 0;
+	for (int i = 0; i < 2 * P; ++i)
+	{
+		maxd = std::fmax(maxd, std::fabs(ref[i] - mf[i]));
+		differing += std::memcmp(&ref[i], &mf[i], sizeof(double)) != 0;
+	}
+	std::printf("%s: %d residual blocks, %d LM iterations (ebo_solve: %d), %d + %d evaluations, max |flow - ebo_solve| = %.3e, "
+				"%d of %d flow components differ in any bit\n",
+				name, problem.NumResidualBlocks(), st.iterations, sum.iterations, st.evals_cost, st.evals_jac, maxd, differing,
+				2 * P);
+	EXPECT_TRUE(st.iterations == sum.iterations);
+	EXPECT_TRUE(st.evals_cost * problem.NumResidualBlocks() == sum.num_evals_cost ||
+				st.evals_cost == sum.num_evals_cost);
+	EXPECT_TRUE(differing == 0);
+}
+
+int main()
+{
+	runCase(EBO_LOSS_EDGE, "edge loss (the reference's operator())");
+	runCase(EBO_LOSS_VARIANCE, "variance loss");
+	if (failures == 0)
+	{
+		std::printf("all passed\n");
+		return 0;
+	}
+	std::printf("%d failures\n", failures);
+	return 1;
+}

@@ -24,3 +24,26 @@ def test_facade_against_oracle_on_gpu(ebo, orc):
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-3000:]
     assert "all passed" in out.stdout
+
+
+def test_ceres_surface_compiles(ebo):
+    """CPU: the EBO_HAVE_CERES branch of feature_tracker/contrast_functor.h (HipContrastCost, a
+    ceres::SizedCostFunction<1, 2>; ContrastBatch, a ceres::EvaluationCallback) compiles under
+    -Wall -Wextra against the test-only declarations of tests/cpp/stubs/ceres/ceres.h."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "ceres_adaptor_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_ceres_surface_solves_like_ebo_solve(ebo):
+    """The reference's problem construction (feature_detector.cpp:301-367) with HipContrastCost blocks
+    and ContrastBatch as the evaluation callback, minimised by the product's host LM through
+    CostFunction::Evaluate: the same flows as ebo_solve(EBO_SOLVE_GLOBAL), bit for bit, both losses."""
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "ceres_adaptor_test"])
+    out = subprocess.run([os.path.join(CPP, "ceres_adaptor_test")], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "all passed" in out.stdout
