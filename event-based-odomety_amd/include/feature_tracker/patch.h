@@ -80,6 +80,17 @@ class Patch
 		patch_ = Rect2d(newCenterX - extentX, newCenterY - extentY, 2 * extentX + 1, 2 * extentY + 1);
 	}
 
+	// patch.cpp:255-266
+	void setCorner(const Corner& corner, const common::timestamp_t& timestamp)
+	{
+		patch_ = Rect2d(corner.x - (patch_.width - 1) / 2., corner.y - (patch_.height - 1) / 2., patch_.width, patch_.height);
+		initPoint_ = toCorner();
+		init_ = false;
+		currentTimestamp_ = timestamp;
+		addTrajectoryPosition();
+		resetBatch();
+	}
+
 	void resetBatch() { counter_ = 0; }
 	void addTrajectoryPosition() { trajectory_.push_back({toCorner(), currentTimestamp_}); }
 	void addFinalCost(double finalCost) { finalCosts_.emplace_back(finalCost); }

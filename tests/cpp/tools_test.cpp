@@ -1,0 +1,133 @@
+// tools_test.cpp — CPU: the reference's own scenarios for the stream pump and the track file,
+// run against the facade (no GPU: only host entry points of libebo_hip.so are called).
+//   tools/replayer/test/replayer_test.cpp:67-125   nextTest, nextImageTest, resetTest on its
+//       test_data (events at 0 and 3 us, images at 1 and 4 us; tests/golden/replayer/ holds the
+//       same two data files)
+//   tools/evaluator/test/evaluator_test.cpp:19-83  saveTrajectoryTest: two patches, 31 trajectory
+//       points each, written as "id ts x y" and parsed back within EXPECT_FLOAT_EQ
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../event-based-odomety_amd/include/tools/evaluator.h"
+#include "../../event-based-odomety_amd/include/tools/event_pump.h"
+
+static int g_fail = 0;
+#define EXPECT_TRUE(c)                                                 \
+	do                                                                 \
+	{                                                                  \
+		if (!(c))                                                      \
+		{                                                              \
+			std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+			++g_fail;                                                  \
+		}                                                              \
+	} while (0)
+
+using Stamp = std::pair<common::timestamp_t, tools::EventType>;
+
+struct TestListener
+{
+	void eventCallback(const common::EventSample& s) { timestamps.emplace_back(s.timestamp, tools::EventType::EVENT); }
+	void imageCallback(const tools::ImageStamp& s) { timestamps.emplace_back(s.timestamp, tools::EventType::IMAGE); }
+	std::vector<Stamp> timestamps;
+};
+
+static tools::StreamPump makeReplayer(const std::string& dir, TestListener& listener)
+{
+	tools::StreamPump pump = tools::StreamPump::fromDirectory(dir);
+	pump.addEventCallback([&listener](const common::EventSample& s) { listener.eventCallback(s); });
+	pump.addImageCallback([&listener](const tools::ImageStamp& s) { listener.imageCallback(s); });
+	return pump;
+}
+
+static void expectStamps(const std::vector<Stamp>& want, const std::vector<Stamp>& got)
+{
+	EXPECT_TRUE(want.size() == got.size());
+	for (size_t i = 0; i < want.size() && i < got.size(); ++i)
+	{
+		EXPECT_TRUE(want[i].first == got[i].first);
+		EXPECT_TRUE(want[i].second == got[i].second);
+	}
+}
+
+int main(int argc, char** argv)
+{
+	const std::string dir = argc > 1 ? argv[1] : "../golden/replayer";
+	const std::vector<Stamp> all = {{common::timestamp_t(0), tools::EventType::EVENT},
+									{common::timestamp_t(1), tools::EventType::IMAGE},
+									{common::timestamp_t(3), tools::EventType::EVENT},
+									{common::timestamp_t(4), tools::EventType::IMAGE}};
+	{  // nextTest
+		TestListener listener;
+		tools::StreamPump replayer = makeReplayer(dir, listener);
+		while (!replayer.finished())
+		{
+			replayer.next();
+		}
+		expectStamps(all, listener.timestamps);
+	}
+	{  // nextImageTest
+		TestListener listener;
+		tools::StreamPump replayer = makeReplayer(dir, listener);
+		replayer.nextImage();
+		replayer.nextImage();
+		expectStamps(all, listener.timestamps);
+	}
+	{  // resetTest
+		TestListener listener;
+		tools::StreamPump replayer = makeReplayer(dir, listener);
+		replayer.nextInterval(common::timestamp_t(3));
+		replayer.reset();
+		listener.timestamps.clear();
+		replayer.next();
+		expectStamps({{common::timestamp_t(0), tools::EventType::EVENT}}, listener.timestamps);
+	}
+	{  // saveTrajectoryTest
+		tracker::Patches patches;
+		std::vector<std::pair<int, common::Sample<common::Point2d>>> trajectories;
+		for (int i = 0; i < 2; ++i)
+		{
+			tracker::Patch patch({0, 0}, 10, common::timestamp_t(0));
+			patch.setTrackId(i);
+			trajectories.push_back({patch.getTrackId(), common::Sample<common::Point2d>{{0, 0}, common::timestamp_t(0)}});
+			for (int j = 0; j < 30; ++j)
+			{
+				common::Sample<common::Point2d> sample;
+				sample.value = common::Point2d(j, j);
+				sample.timestamp = common::timestamp_t(j);
+				patch.setCorner(sample.value, sample.timestamp);
+				trajectories.push_back({patch.getTrackId(), sample});
+			}
+			patches.push_back(patch);
+		}
+		const std::string out = "/tmp/ebo_tools_test_trajectory.txt";
+		tools::saveFeaturesTrajectory(patches, out);
+		std::ifstream file(out);
+		EXPECT_TRUE(static_cast<bool>(file));
+		std::vector<std::tuple<size_t, double, double, double>> parsed;
+		size_t id;
+		double ts, x, y;
+		while (file >> id >> ts >> x >> y)
+		{
+			parsed.emplace_back(id, ts, x, y);
+		}
+		EXPECT_TRUE(parsed.size() == trajectories.size());
+		auto floatEq = [](double a, double b) {  // EXPECT_FLOAT_EQ: within 4 ulps of float
+			const float fa = static_cast<float>(a), fb = static_cast<float>(b);
+			return std::fabs(fa - fb) <= 4 * 1.1920929e-7f * std::fmax(std::fabs(fa), std::fabs(fb));
+		};
+		for (size_t i = 0; i < parsed.size() && i < trajectories.size(); ++i)
+		{
+			std::tie(id, ts, x, y) = parsed[i];
+			EXPECT_TRUE(floatEq(std::chrono::duration<double>(trajectories[i].second.timestamp).count(), ts));
+			EXPECT_TRUE(floatEq(x, trajectories[i].second.value.x));
+			EXPECT_TRUE(floatEq(y, trajectories[i].second.value.y));
+			EXPECT_TRUE(static_cast<int>(id) == trajectories[i].first);
+		}
+	}
+	std::printf(g_fail ? "tools_test: %d FAILED\n" : "tools_test: all passed\n", g_fail);
+	return g_fail ? 1 : 0;
+}

@@ -47,3 +47,15 @@ def test_ceres_surface_solves_like_ebo_solve(ebo):
     print(out.stdout[-3000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-3000:]
     assert "all passed" in out.stdout
+
+
+def test_reference_replayer_and_trajectory_scenarios(ebo):
+    """CPU: tools/replayer/test/replayer_test.cpp:67-125 (nextTest, nextImageTest, resetTest on the
+    reference's own two data files) through tools::StreamPump, and
+    tools/evaluator/test/evaluator_test.cpp:19-83 (saveTrajectoryTest) through
+    tools::saveFeaturesTrajectory -- host entry points only, no GPU."""
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "tools_test"])
+    out = subprocess.run([os.path.join(CPP, "tools_test"), os.path.join(HERE, "golden", "replayer")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "all passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
