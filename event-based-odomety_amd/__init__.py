@@ -519,6 +519,16 @@ class Context:
             C.byref(opts) if opts is not None else None, _dp(poses), _dp(flow_dirs), sums))
         return poses, flow_dirs, list(sums)[:n]
 
+    def estimate_num_events(self, rects, poses, flow_dirs):
+        """FeatureDetector::updateNumOfEvents' event-count estimate for n tracked patches."""
+        rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
+        flow_dirs = np.ascontiguousarray(flow_dirs, dtype=np.float64).reshape(-1)
+        n = len(rects)
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self._check(lib().ebo_estimate_num_events(self._h, n, _dp(rects), _dp(poses), _dp(flow_dirs), _vp(out)))
+        return out[:n]
+
     # -- tracked-feature patches (Patch::integrate*) --------------------------
     def patch_integrate(self, ev, offsets, rects):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)

@@ -2990,6 +2990,18 @@ int launch_optimizer_interleave(const double* d_gx, const double* d_gy, size_t n
 	return check_launch();
 }
 
+int launch_estimate_num_events(const double2* d_grid, int w, int h, int n, const double* d_rects, const double* d_poses,
+								const double* d_flows, double* d_sums, void* stream)
+{
+	if (n <= 0)
+	{
+		return 0;
+	}
+	hipLaunchKernelGGL(k_estimate_num_events, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), d_grid, w, h, n,
+					   d_rects, d_poses, d_flows, d_sums);
+	return check_launch();
+}
+
 template <class Rec>
 static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 {

@@ -349,6 +349,63 @@ int ebo_optimizer_set_grad(ebo_ctx* c, const double* grad_x, const double* grad_
 	return rc;
 }
 
+// FeatureDetector::updateNumOfEvents' estimate (feature_detector.cpp:689-707) for n patches, one launch.
+int ebo_estimate_num_events(ebo_ctx* c, int n, const double* rects, const double* poses, const double* flow_dirs,
+							uint64_t* out)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (n < 0 || (n && (!rects || !poses || !flow_dirs || !out)))
+	{
+		return c->fail(EBO_ERR_ARG, "null argument");
+	}
+	if (!c->opt_grid_valid)
+	{
+		return c->fail(EBO_ERR_STATE, "no gradient grid: call ebo_optimizer_set_grad first");
+	}
+	if (n == 0)
+	{
+		return EBO_OK;
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t nn = static_cast<size_t>(n);
+	int rc = ensure_scratch(c, nn * 10 * sizeof(double));
+	if (rc)
+	{
+		return rc;
+	}
+	double* d = static_cast<double*>(c->d_scratch);
+	double* dRects = d;
+	double* dPoses = d + 4 * nn;
+	double* dFlows = d + 8 * nn;
+	double* dSums = d + 9 * nn;
+	hipError_t e = hipMemcpyAsync(dRects, rects, 4 * nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dPoses, poses, 4 * nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dFlows, flow_dirs, nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D estimate arguments");
+	}
+	if (launch_estimate_num_events(c->d_opt_grid, c->prm.image_w, c->prm.image_h, n, dRects, dPoses, dFlows, dSums, c->stream))
+	{
+		return c->hip(hipGetLastError(), "estimate launch");
+	}
+	std::vector<double> sums(nn);
+	e = hipMemcpyAsync(sums.data(), dSums, nn * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "D2H estimates");
+	}
+	for (size_t i = 0; i < nn; ++i)
+	{
+		out[i] = static_cast<uint64_t>(sums[i]);  // size_t sumPatch = cv::norm(...)
+	}
+	return EBO_OK;
+}
+
 namespace
 {
 struct OptBuffers

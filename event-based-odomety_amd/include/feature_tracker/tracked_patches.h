@@ -17,11 +17,13 @@
 //        round routes the rest of the chunk from where each patch stopped.  Per patch the sequence
 //        of addEvent / optimize calls is exactly the per-event one.
 //
-// Not built: the event-count estimate of updateNumOfEvents (:689-707), which warps the whole
-// gradient images with cv::warpAffine (OpenCV's fixed-point bilinear tables) and sums them over
-// the rect; its two border branches (:668-687) are.  A caller with OpenCV plugs the estimate in
-// with setNumOfEventsEstimator; without one a patch keeps its event count.  Patch::warpImage
-// (a visualisation, :615) is not built.
+// updateNumOfEvents (:666-711) is complete: the two border branches on the host, the event-count
+// estimate (:689-707: cv::warpAffine of gradX_ / gradY_ with flags = WARP_INVERSE_MAP, i.e. nearest
+// neighbour through OpenCV's 10-bit fixed-point map, and the L1 norm over the rect) on the device
+// (ebo_estimate_num_events) from the gradient images given to setGradients -- gradX_ / gradY_ of the
+// latest frame in the reference (:516-517).  setNumOfEventsEstimator overrides it; without gradients
+// and without an estimator a patch keeps its event count.  Patch::warpImage (a visualisation, :615)
+// is not built.
 #pragma once
 
 #include <algorithm>
@@ -73,27 +75,77 @@ class TrackedPatches
 		optimizers_[initTime.count()] = std::move(optimizer);
 	}
 	void setNumOfEventsEstimator(std::function<size_t(const Patch&)> estimator) { estimator_ = std::move(estimator); }
+	// gradX_ / gradY_ of FeatureDetector (set per frame in newImage, :516-517): what updateNumOfEvents warps
+	void setGradients(const Mat64& gradX, const Mat64& gradY)
+	{
+		if (gradX.rows != imageSize_.height || gradX.cols != imageSize_.width || gradY.rows != gradX.rows ||
+			gradY.cols != gradX.cols)
+		{
+			throw std::invalid_argument("gradient images must be imageSize");
+		}
+		check(ebo_optimizer_set_grad(ctx_, gradX.ptr(), gradY.ptr()));
+		haveGradients_ = true;
+	}
 
-	// feature_detector.cpp:666-711
+	// feature_detector.cpp:666-711, one patch
 	void updateNumOfEvents(Patch& patch)
 	{
-		const Rect2d& rect = patch.getPatch();
-		// (rect.tl() + rect.br()) * 0.5
-		const double cx = (rect.x + (rect.x + rect.width)) * 0.5, cy = (rect.y + (rect.y + rect.height)) * 0.5;
-		if (cx <= 5 || cy <= 5 || cx >= imageSize_.width - 5 || cy >= imageSize_.height - 5)
+		std::vector<Patch*> one(1, &patch);
+		updateNumOfEvents(one);
+	}
+
+	// the same for several patches: the border branches per patch, ONE launch for the estimates
+	void updateNumOfEvents(const std::vector<Patch*>& patches)
+	{
+		std::vector<Patch*> need;
+		for (Patch* pp : patches)
 		{
-			patch.setLost();
+			Patch& patch = *pp;
+			const Rect2d& rect = patch.getPatch();
+			// (rect.tl() + rect.br()) * 0.5
+			const double cx = (rect.x + (rect.x + rect.width)) * 0.5, cy = (rect.y + (rect.y + rect.height)) * 0.5;
+			if (cx <= 5 || cy <= 5 || cx >= imageSize_.width - 5 || cy >= imageSize_.height - 5)
+			{
+				patch.setLost();
+				continue;
+			}
+			if (rect.x < 0 || rect.y < 0 || rect.x + rect.width >= imageSize_.width ||
+				rect.y + rect.height >= imageSize_.height)
+			{
+				patch.setNumOfEvents(static_cast<size_t>(initNumEvents_));
+				continue;
+			}
+			if (estimator_)
+			{
+				patch.setNumOfEvents(estimator_(patch));
+			}
+			else if (haveGradients_)
+			{
+				need.push_back(pp);
+			}
+		}
+		if (need.empty())
+		{
 			return;
 		}
-		if (rect.x < 0 || rect.y < 0 || rect.x + rect.width >= imageSize_.width ||
-			rect.y + rect.height >= imageSize_.height)
+		const size_t n = need.size();
+		std::vector<double> rects(4 * n), poses(4 * n), flows(n);
+		std::vector<uint64_t> est(n);
+		for (size_t i = 0; i < n; ++i)
 		{
-			patch.setNumOfEvents(static_cast<size_t>(initNumEvents_));
-			return;
+			const Rect2d& r = need[i]->getPatch();
+			rects[4 * i + 0] = r.x;
+			rects[4 * i + 1] = r.y;
+			rects[4 * i + 2] = r.width;
+			rects[4 * i + 3] = r.height;
+			const double* w = need[i]->getWarp().data();
+			std::copy(w, w + 4, &poses[4 * i]);
+			flows[i] = need[i]->getFlow();  // a float in the reference (patch.h:56)
 		}
-		if (estimator_)
+		check(ebo_estimate_num_events(ctx_, static_cast<int>(n), rects.data(), poses.data(), flows.data(), est.data()));
+		for (size_t i = 0; i < n; ++i)
 		{
-			patch.setNumOfEvents(estimator_(patch));
+			need[i]->setNumOfEvents(static_cast<size_t>(est[i]));
 		}
 	}
 
@@ -220,10 +272,7 @@ class TrackedPatches
 					throw std::runtime_error("tracker::TrackedPatches: no optimizer for a patch's init time");
 				}
 				it->second->optimize(group.second);
-				for (Patch* p : group.second)
-				{
-					updateNumOfEvents(*p);  // also after a patch was lost in optimize, as :613-614
-				}
+				updateNumOfEvents(group.second);  // also after a patch was lost in optimize, as :613-614
 			}
 			live.clear();
 			for (int i : still)
@@ -263,6 +312,7 @@ class TrackedPatches
 	Patches patches_;
 	std::map<int64_t, std::shared_ptr<Optimizer>> optimizers_;
 	std::function<size_t(const Patch&)> estimator_;
+	bool haveGradients_ = false;
 	int rounds_ = 0;
 };
 

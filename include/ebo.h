@@ -293,6 +293,18 @@ int ebo_optimizer_eval(ebo_ctx* ctx, int n, const double* rects, const double* n
 int ebo_optimizer_solve(ebo_ctx* ctx, int n, const double* rects, const double* nabla, int normalize, double huber,
 						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries);
 
+/* The event-count estimate of FeatureDetector::updateNumOfEvents (feature_detector.cpp:689-707) for n
+ * tracked patches in one launch: the L1 norm over the patch rect of
+ * 0.6 gradX' cos(flow) + 0.6 gradY' sin(flow), gradX' / gradY' = the gradient images of
+ * ebo_optimizer_set_grad warped by cv::warpAffine(..., patch.getWarp().matrix2x3(),
+ * cv::WARP_INVERSE_MAP) -- flags without interpolation bits: INTER_NEAREST through OpenCV's 10-bit
+ * fixed-point map, BORDER_CONSTANT 0 -- truncated to an integer as `size_t sumPatch = cv::norm(..)`
+ * does.  rects [n][4] = cv::Rect2d, poses [n][4] = Sophus::SE2d::data(), flow_dirs [n], out [n].
+ * The two border branches of updateNumOfEvents (:668-687) are the caller's (the facade has them).
+ * EBO_ERR_STATE without ebo_optimizer_set_grad. */
+int ebo_estimate_num_events(ebo_ctx* ctx, int n, const double* rects, const double* poses, const double* flow_dirs,
+							uint64_t* out);
+
 /* Event -> tracked-patch routing: what FeatureDetector::updatePatches does per event,
  * `if (patch.isInPatch(event.value.point)) patch.addEvent(event)` (feature_detector.cpp:585-596;
  * cv::Rect2d::contains on the integer point: x <= px < x + w, y <= py < y + h in double), for a

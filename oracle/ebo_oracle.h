@@ -227,6 +227,15 @@ int orc_optimizer_solve(const double* grad, int img_w, int img_h, double rx, dou
 int orc_se2_plus(const double* pose, const double* delta3, double* out);
 /* Patch::updatePatchRect (patch.cpp:49-63): rect [4] from warp [4] and the initial centre. */
 int orc_patch_update_rect(const double* warp, double init_x, double init_y, double rw, double rh, double* rect);
+/* The event-count estimate of FeatureDetector::updateNumOfEvents (feature_detector.cpp:689-707):
+ * cv::warpAffine of the two gradient images with flags = cv::WARP_INVERSE_MAP alone, i.e.
+ * INTER_NEAREST through OpenCV's 10-bit fixed-point coordinates, then the L1 norm of
+ * 0.6 gradX cos(flow) + 0.6 gradY sin(flow) over the patch rect, truncated to size_t.  OpenCV is not
+ * in the image: restated from its published algorithm (imgproc/imgwarp.cpp, cv::warpAffine /
+ * WarpAffineInvoker), PARITY UNPINNED; exact by construction for identity and integer-translation
+ * warps.  grad [img_h][img_w][2] = (gradX, gradY); warp [4] = Sophus::SE2d::data(). */
+int orc_estimate_num_events(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+							const double* warp, double flow_dir, uint64_t* out);
 /* Patch::getNormalizedIntegratedNabla (patch.cpp:156-159). */
 int orc_normalize_nabla(const double* nabla, int n, double* out);
 

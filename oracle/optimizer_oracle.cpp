@@ -928,6 +928,51 @@ int orc_se2_plus(const double* pose, const double* delta3, double* out)
 	return 0;
 }
 
+// cv::warpAffine(src, dst, M, size, cv::WARP_INVERSE_MAP) as FeatureDetector::updateNumOfEvents
+// calls it (feature_detector.cpp:697-700): no interpolation bits in the flags = INTER_NEAREST;
+// WARP_INVERSE_MAP = M maps DESTINATION pixels to source positions as given.  OpenCV evaluates the
+// map in fixed point (imgwarp.cpp): AB_BITS = 10, adelta[x] = cvRound(M[0] x 1024), bdelta[x] =
+// cvRound(M[3] x 1024), per row X0 = cvRound((M[1] y + M[2]) 1024) + 512, Y0 likewise, source pixel
+// (X0 + adelta[x]) >> 10, (Y0 + bdelta[x]) >> 10, BORDER_CONSTANT 0 outside.  cvRound = lrint
+// (round half to even).  Then warped(rect): cv::Rect2d -> cv::Rect by saturate_cast = cvRound of
+// x, y, width, height; cv::norm(0.6 gradX cos + 0.6 gradY sin, NORM_L1): the MatExpr scales are
+// folded, (0.6 * cos) and (0.6 * sin), one a*x + b*y per pixel, summed row-major; size_t truncates.
+int orc_estimate_num_events(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+							const double* warp, double flow_dir, uint64_t* out)
+{
+	if (!grad || !warp || !out || img_w <= 0 || img_h <= 0)
+	{
+		return -1;
+	}
+	// matrix2x3 of SE2 (c, s, tx, ty): [c -s tx; s c ty]
+	const double M[6] = {warp[0], -warp[1], warp[2], warp[1], warp[0], warp[3]};
+	const int x0 = static_cast<int>(std::lrint(rx)), y0 = static_cast<int>(std::lrint(ry));
+	const int w = static_cast<int>(std::lrint(rw)), h = static_cast<int>(std::lrint(rh));
+	// `const auto flow = patch.getFlow();` is a float (patch.h:56): float cos / sin, widened
+	const float ff = static_cast<float>(flow_dir);
+	const double a = 0.6 * static_cast<double>(std::cos(ff)), b = 0.6 * static_cast<double>(std::sin(ff));
+	double sum = 0.0;
+	for (int y = y0; y < y0 + h; ++y)
+	{
+		const int X0 = static_cast<int>(std::lrint((M[1] * y + M[2]) * 1024.0)) + 512;
+		const int Y0 = static_cast<int>(std::lrint((M[4] * y + M[5]) * 1024.0)) + 512;
+		for (int x = x0; x < x0 + w; ++x)
+		{
+			const int X = (X0 + static_cast<int>(std::lrint(M[0] * x * 1024.0))) >> 10;
+			const int Y = (Y0 + static_cast<int>(std::lrint(M[3] * x * 1024.0))) >> 10;
+			double gx = 0.0, gy = 0.0;
+			if (x >= 0 && x < img_w && y >= 0 && y < img_h && X >= 0 && X < img_w && Y >= 0 && Y < img_h)
+			{
+				gx = grad[2 * (static_cast<size_t>(Y) * img_w + X)];
+				gy = grad[2 * (static_cast<size_t>(Y) * img_w + X) + 1];
+			}
+			sum += std::fabs(gx * a + gy * b);
+		}
+	}
+	*out = static_cast<uint64_t>(sum);
+	return 0;
+}
+
 int orc_patch_update_rect(const double* warp, double init_x, double init_y, double rw, double rh, double* rect)
 {
 	if (!warp || !rect)

@@ -558,11 +558,23 @@ int main()
 				gy.at<double>(y, x) = vy;
 			}
 		}
+		// the detector's own gradient images for the event-count estimate, scaled so that the estimates
+		// land inside Patch::setNumOfEvents' clamp [100, 300] and differ from patch to patch
+		tracker::Mat64 gxBig(H, W), gyBig(H, W);
+		for (int y = 0; y < H; ++y)
+		{
+			for (int x = 0; x < W; ++x)
+			{
+				gxBig.at<double>(y, x) = 4.0 * gx.at<double>(y, x) + 0.25 + 0.001 * x;
+				gyBig.at<double>(y, x) = 4.0 * gy.at<double>(y, x) - 0.2 + 0.0015 * y;
+			}
+		}
 		tracker::OptimizerParams op;
 		auto build = [&](tracker::TrackedPatches& tp) {
 			auto opt = std::make_shared<tracker::Optimizer>(op, tracker::Size(W, H));
 			opt->setGrad(gx, gy);
 			tp.setOptimizer(common::timestamp_t(1000), opt);
+			tp.setGradients(gxBig, gyBig);  // gradX_ / gradY_ of the detector: updateNumOfEvents' estimate runs on the device
 			for (int k = 0; k < 4; ++k)
 			{
 				tracker::Patch p(tracker::Corner(42.0 + 38 * k, 38.0 + 25 * k), 12, common::timestamp_t(1000));
@@ -628,6 +640,7 @@ int main()
 					optSeq->getFinalCosts().size(), optBat->getFinalCosts().size(), roundsA, bat.lastRounds());
 		EXPECT_TRUE(optSeq->getFinalCosts().size() == optBat->getFinalCosts().size());
 		EXPECT_TRUE(optSeq->getFinalCosts().size() >= 8);
+		int adapted = 0;
 		for (size_t i = 0; i < seq.getPatches().size(); ++i)
 		{
 			const tracker::Patch& p = seq.getPatches()[i];
@@ -637,6 +650,30 @@ int main()
 			EXPECT_TRUE(p.getTrajectory().size() == q.getTrajectory().size());
 			EXPECT_TRUE(p.getEvents().size() == q.getEvents().size());
 			EXPECT_TRUE(p.eventsUntilReady() == q.eventsUntilReady());
+			EXPECT_TRUE(p.getNumOfEvents() == q.getNumOfEvents());
+			if (!p.isLost() && p.isInit() && !p.getFinalCosts().empty())
+			{
+				// updateNumOfEvents' estimate at the patch's final state, against the oracle's restatement
+				std::vector<double> interleaved(2 * static_cast<size_t>(W) * H);
+				for (int yy = 0; yy < H; ++yy)
+				{
+					for (int xx = 0; xx < W; ++xx)
+					{
+						interleaved[2 * (static_cast<size_t>(yy) * W + xx)] = gxBig.at<double>(yy, xx);
+						interleaved[2 * (static_cast<size_t>(yy) * W + xx) + 1] = gyBig.at<double>(yy, xx);
+					}
+				}
+				uint64_t est = 0;
+				const tracker::Rect2d& rr = p.getPatch();
+				orc_estimate_num_events(interleaved.data(), W, H, rr.x, rr.y, rr.width, rr.height, p.getWarp().data(), p.getFlow(), &est);
+				const size_t clamped = std::min<size_t>(std::max<size_t>(est, 100), 300);
+				const bool inside = !(rr.x < 0 || rr.y < 0 || rr.x + rr.width >= W || rr.y + rr.height >= H);
+				if (inside)
+				{
+					EXPECT_TRUE(p.getNumOfEvents() == clamped);
+					adapted += p.getNumOfEvents() != 75 ? 1 : 0;
+				}
+			}
 			bool sameEvents = p.getEvents().size() == q.getEvents().size();
 			for (size_t k = 0; sameEvents && k < p.getEvents().size(); ++k)
 			{
@@ -657,6 +694,7 @@ int main()
 			std::printf("  patch %zu: %zu optimisations, lost %d, centre (%.4f, %.4f)\n", i, p.getFinalCosts().size(),
 						int(p.isLost()), p.toCorner().x, p.toCorner().y);
 		}
+		EXPECT_TRUE(adapted >= 3);  // the tracked patches adapt their event count without any estimator hook
 		// timing, 100 tracked patches (25 copies of the four) over the same 6000-event stream
 		{
 			auto many = [&](tracker::TrackedPatches& tp) {

@@ -391,6 +391,18 @@ def optimizer_solve(grad, rect, nabla, pose, flow_dir, huber=0.3, opts=None):
     return p, fd.value, s
 
 
+def estimate_num_events(grad, rect, pose, flow_dir):
+    """The event-count estimate of FeatureDetector::updateNumOfEvents (feature_detector.cpp:689-707)."""
+    grad = np.ascontiguousarray(grad, dtype=np.float64)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    h, w = grad.shape[:2]
+    out = C.c_uint64()
+    rc = lib().orc_estimate_num_events(_dp(grad), w, h, C.c_double(rect[0]), C.c_double(rect[1]), C.c_double(rect[2]),
+                                       C.c_double(rect[3]), _dp(pose), C.c_double(flow_dir), C.byref(out))
+    assert rc == 0
+    return out.value
+
+
 def se2_plus(pose, delta3):
     out = np.zeros(4)
     assert lib().orc_se2_plus(_dp(np.ascontiguousarray(pose, dtype=np.float64)),
