@@ -435,7 +435,7 @@ def main():
 
         units_per_step = float(S["active"])
         kernel_fn = eval_step
-        roof_kernel = "k_eval3<true>"
+        roof_kernel = "k_eval3<true, false>"
         par = ("windows sharded over %d GPU(s), no data-path collective" % world) if workload == "eval" else (
             "%d independent sequences, one per GPU; per step one gather of the per-sequence tracks "
             "(counts + max-padded all-gather)" % world)
