@@ -309,14 +309,36 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	const double sig = c->prm.k.sigma_st;
 	const double sigmaSq = sig * sig;
 	const double normCoef = 1.0 / ((2 * M_PI) * sigmaSq);
-	for (int i = -3; i <= 3; ++i)
+	if (!c->d_edge_w || c->edge_w_sigma != sig)
 	{
-		for (int j = -3; j <= 3; ++j)
+		double w[49];
+		for (int i = -3; i <= 3; ++i)
 		{
-			const double x = j, y = i;
-			L.ec.w[(i + 3) * 7 + (j + 3)] = normCoef * std::exp(-0.5 / sigmaSq * (x * x + y * y));
+			for (int j = -3; j <= 3; ++j)
+			{
+				const double x = j, y = i;
+				w[(i + 3) * 7 + (j + 3)] = normCoef * std::exp(-0.5 / sigmaSq * (x * x + y * y));
+			}
 		}
+		if (!c->d_edge_w)
+		{
+			rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_edge_w), sizeof(w)), "hipMalloc edge weights");
+			if (rc)
+			{
+				return rc;
+			}
+		}
+		// synchronous: the table must not change under a launch still in flight
+		rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+		if (rc == EBO_OK) rc = c->hip(hipMemcpy(c->d_edge_w, w, sizeof(w), hipMemcpyHostToDevice), "H2D edge weights");
+		if (rc)
+		{
+			return rc;
+		}
+		c->edge_w_sigma = sig;
 	}
+	L.ec.w = c->d_edge_w;
+	L.ec.w_max = normCoef;
 	for (int k = -3; k <= 3; ++k)
 	{
 		L.ec.g[k + 3] = std::exp(-0.5 / sigmaSq * static_cast<double>(k * k));
@@ -1550,6 +1572,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_stats);
 	hipFree(c->d_scratch);
 	hipFree(c->d_edge_scratch);
+	hipFree(c->d_edge_w);
 	hipFree(c->d_raw);
 	hipFree(c->d_bucket);
 	hipFree(c->d_field);

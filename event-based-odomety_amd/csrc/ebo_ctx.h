@@ -85,6 +85,8 @@ struct ebo_ctx
 	int32_t* d_stats = nullptr;
 	void* d_scratch = nullptr;  // patch-integrate staging
 	size_t scratch_cap = 0;
+	double* d_edge_w = nullptr;      // the 49 tensor weights of the edge loss (device table)
+	double edge_w_sigma = -1.0;      // sigma_st they were built for
 	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
 	size_t edge_scratch_cap = 0;
 	void* d_field = nullptr;         // motion field of ebo_init_motion_field (+ its staging)

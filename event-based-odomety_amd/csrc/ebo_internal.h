@@ -108,7 +108,8 @@ int launch_dump_image(const EvalLaunch& L, int unit, double* d_image, void* stre
 // Edge (structure-tensor) loss, contrast_functor.h:152-277.
 struct EdgeConsts
 {
-	double w[49];          // tensor weights [i+3][j+3] = gaussian(0,0,j,i,sigmaST) (:193-202)
+	const double* w;       // DEVICE table [49]: tensor weights [i+3][j+3] = gaussian(0,0,j,i,sigmaST) (:193-202); read by scalar loads where used (49 kernel-argument doubles pinned 98 SGPRs and the reverse pass spilled hundreds)
+	double w_max;          // the largest of them, w[24]
 	double g[7];           // 1-D factors exp(hs_st k^2), k = -3..3:  w(i,j) = norm_st g[i] g[j]
 	double norm_st;        // 1 / (2 pi sigmaST^2)
 	double mean_threshold; // 1e-4 (:159)
