@@ -1575,6 +1575,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_edge_w);
 	hipFree(c->d_raw);
 	hipFree(c->d_bucket);
+	hipFree(c->d_chunk_hist);
 	hipFree(c->d_field);
 	hipFree(c->d_tvf);
 	if (c->ev0) hipEventDestroy(c->ev0);

@@ -102,6 +102,8 @@ struct ebo_ctx
 	hipStream_t copy_stream = nullptr;  // uploads of ebo_set_windows / ebo_set_windows8, overlapped with the bucketing
 	hipEvent_t copy_done[8] = {};
 	void* d_bucket = nullptr;        // bucketing scratch
+	unsigned int* d_chunk_hist = nullptr;  // per-chunk bucket histograms / first ranks of the stable scatter
+	size_t chunk_hist_cap = 0;       // in entries
 	size_t bucket_cap = 0;
 
 	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window

@@ -194,7 +194,8 @@ struct BucketLaunch
 	int P;
 	int max_chunks;                    // ceil(max events per window / 2048)
 	unsigned int min_events;
-	int* d_cnt;                        // [n_windows][P+1] scratch (counts, then cursors)
+	int* d_cnt;                        // [n_windows][P+1] scratch (counts)
+	unsigned int* d_chunk_hist;        // [n_windows][max_chunks][P+1]: per-chunk histograms, then the chunks' first ranks
 	long long* d_tmin;                 // [n_windows][P+1]
 	long long* d_tmax;
 	Unit* d_units;                     // out [n_windows][P+1]

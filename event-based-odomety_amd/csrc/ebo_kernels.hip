@@ -3029,7 +3029,7 @@ static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 			return -2;
 		}
 		hipLaunchKernelGGL(k_bucket_count<Rec>, dim3(L.max_chunks, nw), dim3(256), lds, s, raw,
-						   L.d_offsets, w0, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.c);
+						   L.d_offsets, w0, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.d_chunk_hist, L.c);
 		if (check_launch())
 		{
 			return -2;
@@ -3044,19 +3044,30 @@ static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 	}
 	if (L.max_chunks > 0)
 	{
-		hipLaunchKernelGGL(k_bucket_scatter<Rec>, dim3(L.max_chunks, nw), dim3(256), 0, s, raw,
-						   L.d_offsets, w0, L.P, L.d_cnt, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
+		hipLaunchKernelGGL(k_bucket_chunk_scan, dim3((L.P + 1 + 255) / 256, nw), dim3(256), 0, s, L.d_offsets, w0, L.P,
+						   L.max_chunks, L.d_chunk_hist);
+		if (check_launch())
+		{
+			return -2;
+		}
+		const size_t curLds = static_cast<size_t>(L.P + 1) * sizeof(unsigned int);
+		if (allow_big_lds(k_bucket_scatter<Rec>, curLds))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(k_bucket_scatter<Rec>, dim3(L.max_chunks, nw), dim3(64), curLds, s, raw,
+						   L.d_offsets, w0, L.P, L.d_chunk_hist, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
 						   L.d_flag, L.c);
 		if (check_launch())
 		{
 			return -2;
 		}
 		const size_t sortLds = static_cast<size_t>(kSortMax) * sizeof(unsigned long long);
-		if (allow_big_lds(k_bucket_sort, sortLds))
+		if (allow_big_lds(k_bucket_canon, sortLds))
 		{
 			return -2;
 		}
-		hipLaunchKernelGGL(k_bucket_sort, dim3(nw * (L.P + 1)), dim3(256), sortLds, s,
+		hipLaunchKernelGGL(k_bucket_canon, dim3(nw * (L.P + 1)), dim3(256), sortLds, s,
 						   L.d_units + static_cast<size_t>(w0) * (L.P + 1), L.d_packed);
 	}
 	return check_launch();

@@ -68,6 +68,26 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	L.n_windows = n_windows;
 	L.P = P;
 	L.max_chunks = static_cast<int>((maxWin + 2047) / 2048);
+	{
+		// [windows][chunks][P + 1] counters of the stable scatter: events x (P + 1) / 512 bytes
+		const size_t needHist = static_cast<size_t>(n_windows) * std::max(L.max_chunks, 1) * (P + 1);
+		if (needHist > c->chunk_hist_cap)
+		{
+			if (c->d_chunk_hist)
+			{
+				hipFree(c->d_chunk_hist);
+				c->d_chunk_hist = nullptr;
+				c->chunk_hist_cap = 0;
+			}
+			int rch = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_chunk_hist), needHist * sizeof(unsigned int)), "hipMalloc chunk histograms");
+			if (rch)
+			{
+				return rch;
+			}
+			c->chunk_hist_cap = needHist;
+		}
+		L.d_chunk_hist = c->d_chunk_hist;
+	}
 	L.min_events = c->prm.min_events;
 	L.d_units = c->d_units;
 	L.d_unit_maxdt = c->d_unit_maxdt;
