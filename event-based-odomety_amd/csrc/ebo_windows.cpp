@@ -16,6 +16,7 @@ extern "C" {
 static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* offsets, int n_windows, int compact = 0,
 								 const int64_t* t_base = nullptr, const void* h_src = nullptr)
 {
+	const auto tStart = std::chrono::steady_clock::now();
 	const size_t total = offsets[n_windows] - offsets[0];
 	const int P = c->P;
 	const size_t nUnits = static_cast<size_t>(n_windows) * (P + 1);
@@ -145,7 +146,7 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	}
 	else
 	{
-		// groups of whole windows, each at least ~8 MB, at most 8 groups
+		// groups of whole windows, each at least ~8 MB
 		if (!c->copy_stream)
 		{
 			rc = c->hip(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "copy stream");
@@ -158,7 +159,10 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 				return rc;
 			}
 		}
-		const size_t perGroup = std::max<size_t>((total * recBytes + 7) / 8, static_cast<size_t>(8) << 20);
+		// three groups: 12.8 M compact events take 2.63 / 2.40 / 2.34 / 2.37 / 2.88 ms in 1 / 2 / 3 / 4 / 8 groups
+		// (every group is five launches and two event hand-offs; a plain copy of the bytes 1.79 ms)
+		const size_t wantGroups = std::min<size_t>(std::max<size_t>(env_size("EBO_INGEST_GROUPS", 3), 1), 7);
+		const size_t perGroup = std::max<size_t>((total * recBytes + wantGroups - 1) / wantGroups, static_cast<size_t>(8) << 20);
 		int w0 = 0, g = 0;
 		// the upload may not overtake earlier work of the context's stream that still reads d_raw
 		hipError_t he = hipEventRecord(c->copy_done[7], c->stream);
@@ -201,9 +205,18 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 			return c->hip(he, "pipelined upload");
 		}
 	}
+	const bool trace = std::getenv("EBO_INGEST_TRACE") != nullptr;
+	const auto tIssued = std::chrono::steady_clock::now();
 	hipError_t e = hipMemcpyAsync(pin + bOff, c->d_units, nUnits * sizeof(Unit), hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(pin + bOff + pUnits, L.d_unit_tref, tail, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (trace)
+	{
+		const auto tDone = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[ebo ingest] issue %.3f ms, wait %.3f ms\n",
+					 std::chrono::duration<double, std::milli>(tIssued - tStart).count(),
+					 std::chrono::duration<double, std::milli>(tDone - tIssued).count());
+	}
 	if (e != hipSuccess)
 	{
 		c->n_windows = 0;

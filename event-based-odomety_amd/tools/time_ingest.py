@@ -48,6 +48,17 @@ rows = [
     ("24 B resident      -> device bucketing", lambda: ctx.set_windows_device(d24.data_ptr(), offsets)),
     ("8 B resident       -> device bucketing", lambda: ctx.set_windows8(d8.data_ptr(), t_base, offsets, device=True)),
 ]
+def copy8():
+    d8.copy_(pin8, non_blocking=True)
+    torch.cuda.synchronize()
+
+
+def copy8_pageable():
+    d8.copy_(torch.from_numpy(ev8.view(np.uint8).reshape(-1, 8)))
+    torch.cuda.synchronize()
+
+
+rows += [("(plain copy of the 8 B records, pinned)", copy8), ("(plain copy of the 8 B records, pageable)", copy8_pageable)]
 for name, fn in rows:
     t = best(fn)
     print("cfg %d x %d windows (%d events): %-40s %7.3f ms  %8.0f Mev/s" % (config, Wn, n, name, t * 1e3, n / t / 1e6), flush=True)
