@@ -3191,6 +3191,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		// tile measured 3-4 points of HBM fraction worse at C3 and C4), even width (two 16-bit
 		// counters of a dword never straddle rows), cost = expected tiles a unit visits
 		const int pw = L.c.patch_w, ph = L.c.patch_h;
+		int coarseTiles = 1 << 30;
 		for (int tx = 1; tx <= 16 && ctlBytes <= 48 * 1024; ++tx)
 		{
 			int tw = (W + tx - 1) / tx;
@@ -3204,29 +3205,45 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			{
 				continue;
 			}
-			const int ty = (H + thMax - 1) / thMax;
-			const int th = (H + ty - 1) / ty;
+			const int tyMin = (H + thMax - 1) / thMax;
+			coarseTiles = std::min(coarseTiles, tx * tyMin);
 			const double Rx = 0.5 * pw + 12.0, Ry = 0.5 * ph + 12.0;
-			const double cost = (tx > 1 ? (tw + 2 * Rx) / tw : 1.0) * (ty > 1 ? (th + 2 * Ry) / th : 1.0);
-			if (cost < bestCost - 1e-9)
+			// more, smaller tiles than the LDS asks for when the launch would not fill the chip (two
+			// 1024-lane workgroups per CU = 512): the visits a finer split adds against the CUs it wakes
+			for (int ty = tyMin; ty <= H / 8; ty = (ty < 4 ? ty + 1 : ty * 2))
 			{
-				bestCost = cost;
-				bestX = tx;
-				bestY = ty;
-				bestW = tw;
-				bestH = th;
-				bestBytes = (static_cast<size_t>(tw) * th * b + 15) & ~size_t(15);
+				const int th = (H + ty - 1) / ty;
+				const double visits = (tx > 1 ? (tw + 2 * Rx) / tw : 1.0) * (ty > 1 ? (th + 2 * Ry) / th : 1.0);
+				const double idle = std::max(1.0, 512.0 / (static_cast<double>(L.n_windows) * tx * ty));
+				const double cost = visits * idle;
+				if (cost < bestCost - 1e-9)
+				{
+					bestCost = cost;
+					bestX = tx;
+					bestY = ty;
+					bestW = tw;
+					bestH = th;
+					bestBytes = (static_cast<size_t>(tw) * th * b + 15) & ~size_t(15);
+				}
+				if (idle <= 1.0)
+				{
+					break;  // the chip is full: finer only costs visits
+				}
 			}
 		}
-		const long wgs = static_cast<long>(L.n_windows) * bestX * bestY;
-		if (bestX > 0 && (L.impl == 5 || (bestX * bestY > 1 && wgs >= 64)))
+		// eligibility as before the finer splits existed: the coarsest split the LDS allows must already
+		// give the launch 64 workgroups (single windows and tiny batches stay with impl 0 / 1)
+		const long coarse = static_cast<long>(L.n_windows) * coarseTiles;
+		if (bestX > 0 && (L.impl == 5 || (coarseTiles > 1 && coarse >= 64)))
 		{
 			auto kern = k_count_tiles;
 			const size_t lds = bestBytes + ctlBytes;
 			if (lds <= 160 * 1024 && allow_big_lds(kern, lds) == 0)
 			{
 				const int groups = (L.n_windows + 7) / 8;
-				hipLaunchKernelGGL(kern, dim3(groups * bestX * bestY * 8), dim3(1024), lds, s, L.d_events, L.d_units,
+				const char* be = std::getenv("EBO_COUNT_BLOCK");
+				const int tileBlock = be && *be ? std::max(64, std::min(1024, (std::atoi(be) / 64) * 64)) : 1024;
+				hipLaunchKernelGGL(kern, dim3(groups * bestX * bestY * 8), dim3(tileBlock), lds, s, L.d_events, L.d_units,
 								   L.d_unit_maxdt, L.units_per_window, static_cast<const double*>(L.d_aux), bestW, bestH, bestX,
 								   bestY, static_cast<int>(bestBytes), L.n_windows, L.d_image, L.c);
 				if (check_launch())

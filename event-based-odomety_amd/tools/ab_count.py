@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 ebo = importlib.import_module("event-based-odomety_amd")
 synth = importlib.import_module("event-based-odomety_amd.synth")
 
-KEYS = ("EBO_COUNT_IMPL", "EBO_COUNT_LDS_KB")
+KEYS = ("EBO_COUNT_IMPL", "EBO_COUNT_LDS_KB", "EBO_COUNT_BLOCK")
 
 
 def main():

@@ -1,6 +1,8 @@
 """Throughput floors, far below what is measured but far above anything a slow
 fallback could reach: the evaluation kernel at >= 5 Gevents/s (measured 20), the un-warped count
-image at >= 1 TB/s algorithmic (measured 5.3).  Timed with HIP events on the context's stream."""
+image at >= 1 TB/s algorithmic (measured 5.3), the warped one at >= 0.8 (measured 4+ on large
+batches), the resident window set-up at >= 1.5 Gevents/s.  Timed with HIP events on the context's
+stream (the set-up with the host clock: it ends in a synchronisation)."""
 import numpy as np
 import pytest
 import torch
@@ -36,9 +38,25 @@ def test_hot_kernels_run_at_device_speed(ebo, synth):
 
         t_eval = timed(lambda: c.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr()))
         t_cnt = timed(lambda: c.count_image_device(ebo.COUNT_INTEGRATED, 0, d_img.data_ptr()))
+        d_gt = torch.from_numpy(gt).to("cuda")
+        t_warp = timed(lambda: c.count_image_device(ebo.COUNT_WARPED, d_gt.data_ptr(), d_img.data_ptr()))
         gev = len(ev) / t_eval / 1e9
         tbs = (8 * len(ev) + 8 * d_img.numel()) / t_cnt / 1e12
-        print("eval %.1f Gevents/s, integrateEvents %.2f TB/s" % (gev, tbs))
+        tbw = (8 * len(ev) + 8 * d_img.numel()) / t_warp / 1e12
+        # window set-up from resident 8-byte records (device bucketing without a sort; measured 15-17 G/s
+        # on 12.8 M events, ~8 on this small batch)
+        t_base = np.array([int(ev["t_us"][int(offsets[w])]) for w in range(n_windows)], dtype=np.int64)
+        ev8 = np.concatenate([ebo.pack_events8(ev[int(offsets[w]):int(offsets[w + 1])], t_base[w]) for w in range(n_windows)])
+        d8 = torch.from_numpy(ev8.view(np.uint8).reshape(-1, 8)).to("cuda")
+        import time
+        c.set_windows8(d8.data_ptr(), t_base, offsets, device=True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            c.set_windows8(d8.data_ptr(), t_base, offsets, device=True)
+        gset = len(ev) / ((time.perf_counter() - t0) / 5) / 1e9
+        print("eval %.1f Gevents/s, integrateEvents %.2f TB/s, warped count %.2f TB/s, set-up %.1f Gevents/s" % (gev, tbs, tbw, gset))
         assert np.isfinite(d_out.cpu().numpy()).all()
         assert gev >= 5.0, gev
         assert tbs >= 1.0, tbs
+        assert tbw >= 0.8, tbw
+        assert gset >= 1.5, gset
