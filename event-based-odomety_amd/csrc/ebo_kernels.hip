@@ -42,18 +42,58 @@ __device__ __forceinline__ bool convertible(double c)
 	return fabs(c) < 1073741824.0;  // int(double) is defined; same guard as the CPU path
 }
 
-__device__ __forceinline__ double wave_sum(double v)
+// Wave-wide reductions on the DPP path (no LDS round trip: __shfl_down is a ds_bpermute, ~100
+// cycles of latency per step on the queue the LDS atomics use).  The source lanes of one step:
+// quad neighbours, the other pair of the quad, 4 and 8 lanes down the row of 16, then lane 15 of
+// the previous row into rows 1 and 3 and lane 31 into rows 2 and 3.  A lane with no source gets
+// `idle` (the operation's identity).  The wave's result is in LANE 63 (kWaveResultLane).
+constexpr int kWaveResultLane = 63;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_take(int v, int idle)
 {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
-	{
-		v += __shfl_down(v, off, 64);
-	}
+	return __builtin_amdgcn_update_dpp(idle, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v, double idle)
+{
+	const int lo = dpp_take<CTRL, ROW_MASK>(__double2loint(v), __double2loint(idle));
+	const int hi = dpp_take<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(idle));
+	return __hiloint2double(hi, lo);
+}
+
+// v <- op(v, source lane's v) over the six steps; Op(a, b) must be commutative and associative
+// up to what the caller tolerates (sums: a fixed order, so results are reproducible run to run).
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, T idle, Op op)
+{
+	v = op(v, dpp_take<0xb1, 0xf>(v, idle));   // quad_perm [1,0,3,2]
+	v = op(v, dpp_take<0x4e, 0xf>(v, idle));   // quad_perm [2,3,0,1]
+	v = op(v, dpp_take<0x114, 0xf>(v, idle));  // row_shr 4
+	v = op(v, dpp_take<0x118, 0xf>(v, idle));  // row_shr 8
+	v = op(v, dpp_take<0x142, 0xa>(v, idle));  // row_bcast 15 into rows 1, 3
+	v = op(v, dpp_take<0x143, 0xc>(v, idle));  // row_bcast 31 into rows 2, 3
 	return v;
 }
 
+__device__ __forceinline__ double wave_sum(double v)  // total in lane kWaveResultLane
+{
+	return wave_reduce(v, 0.0, [](double a, double b) { return a + b; });
+}
+
+__device__ __forceinline__ int wave_min(int v)
+{
+	return wave_reduce(v, 0x7fffffff, [](int a, int b) { return min(a, b); });
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+	return wave_reduce(v, static_cast<int>(0x80000000u), [](int a, int b) { return max(a, b); });
+}
+
 // Sums NV per-thread values over the workgroup; every thread gets the totals.
-// Order is fixed (lanes by shuffle tree, then waves 0..nw-1) => deterministic.
+// Order is fixed (lanes by the DPP tree of wave_reduce, then waves 0..nw-1) => deterministic.
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
 {
@@ -66,7 +106,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
 		v[k] = wave_sum(v[k]);
 	}
 	__syncthreads();  // red may still be read by a previous call
-	if (lane == 0)
+	if (lane == kWaveResultLane)
 	{
 #pragma unroll
 		for (int k = 0; k < NV; ++k)
@@ -318,16 +358,12 @@ __device__ __forceinline__ void block_minmax(int& xmin, int& xmax, int& ymin, in
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	const int nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
-	{
-		xmin = min(xmin, __shfl_down(xmin, off, 64));
-		xmax = max(xmax, __shfl_down(xmax, off, 64));
-		ymin = min(ymin, __shfl_down(ymin, off, 64));
-		ymax = max(ymax, __shfl_down(ymax, off, 64));
-	}
+	xmin = wave_min(xmin);
+	xmax = wave_max(xmax);
+	ymin = wave_min(ymin);
+	ymax = wave_max(ymax);
 	__syncthreads();
-	if (lane == 0)
+	if (lane == kWaveResultLane)
 	{
 		ired[wave * 4 + 0] = xmin;
 		ired[wave * 4 + 1] = xmax;
@@ -3486,3 +3522,27 @@ int launch_patch_integrate(const PatchIntLaunch& L, void* stream)
 }
 
 }  // namespace ebo
+
+#ifdef EBO_EDGE_TIMING
+// Phase clocks of the edge kernel (instrumented build only; see ebo_edge.inc).
+extern "C" int ebo_debug_edge_clocks(unsigned long long* out16, int reset)
+{
+	if (hipDeviceSynchronize() != hipSuccess)
+	{
+		return -1;
+	}
+	if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(ebo::g_edge_clk), 16 * sizeof(unsigned long long)) != hipSuccess)
+	{
+		return -1;
+	}
+	if (reset)
+	{
+		unsigned long long zero[16] = {0};
+		if (hipMemcpyToSymbol(HIP_SYMBOL(ebo::g_edge_clk), zero, sizeof(zero)) != hipSuccess)
+		{
+			return -1;
+		}
+	}
+	return 0;
+}
+#endif
