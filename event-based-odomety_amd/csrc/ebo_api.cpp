@@ -344,6 +344,35 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 		L.ec.g[k + 3] = std::exp(-0.5 / sigmaSq * static_cast<double>(k * k));
 	}
 	L.ec.norm_st = normCoef;
+	// Eigenvector directions per pixel for the reverse pass (16 B per LDS-resident pixel and unit, in
+	// HBM / L2): spares every argmax entry the re-derivation of its tensor sums.  Beyond 4 GiB
+	// (EBO_EDGE_CS_MB) the reverse pass re-derives them instead.
+	L.ec.cs = nullptr;
+	L.ec.cs_stride = L.cap_px;
+	{
+		const size_t need = static_cast<size_t>(L.n_units) * L.cap_px * 2 * sizeof(double);
+		const size_t limit = env_size("EBO_EDGE_CS_MB", 4096) << 20;
+		if (L.want_jac && L.flow_sets == 1 && need <= limit && need > 0)
+		{
+			if (need > c->edge_cs_cap)
+			{
+				if (c->d_edge_cs)
+				{
+					c->hip(hipStreamSynchronize(c->stream), "sync");
+					hipFree(c->d_edge_cs);
+					c->d_edge_cs = nullptr;
+					c->edge_cs_cap = 0;
+				}
+				rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_edge_cs), need), "hipMalloc edge directions");
+				if (rc)
+				{
+					return rc;
+				}
+				c->edge_cs_cap = need;
+			}
+			L.ec.cs = c->d_edge_cs;
+		}
+	}
 	L.ec.mean_threshold = 0.0001;
 	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
 	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 7));  // forms of the separable tensor filter (see EdgeConsts / ebo_edge.inc)
@@ -1573,6 +1602,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_scratch);
 	hipFree(c->d_edge_scratch);
 	hipFree(c->d_edge_w);
+	hipFree(c->d_edge_cs);
 	hipFree(c->d_raw);
 	hipFree(c->d_bucket);
 	hipFree(c->d_chunk_hist);

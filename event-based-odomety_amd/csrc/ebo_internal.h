@@ -114,6 +114,8 @@ struct EdgeConsts
 	double norm_st;        // 1 / (2 pi sigmaST^2)
 	double mean_threshold; // 1e-4 (:159)
 	int ablate;            // timing-only ablation mask (EBO_EDGE_ABLATE): 1 eigen, 2 NMS, 4 reverse, 8 gather, 16 scatter
+	double* cs;            // DEVICE table [unit][cap_px][2] or null: (s00 - s11)/d and 2 s01/d of every pixel with a positive eigenvalue, written by the eigenvalue pass of a Jacobian evaluation, read by its reverse pass for the argmax pixels (null: the reverse pass re-derives the tensor sums)
+	int cs_stride;         // pixels per unit in cs (= cap_px)
 	int reserved;          // tensor filter forms (EBO_EDGE_SEPARABLE): 1 band buffers on the 28 B layout, 2 register runs on the 20 B layout, 4 register runs on the 28 B layout
 };
 

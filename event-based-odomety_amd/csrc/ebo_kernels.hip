@@ -37,6 +37,50 @@ __device__ __forceinline__ void unpack(uint64_t rec, int& x, int& y, int& pos, i
 	pos = (lo >> 15) & 1u;
 }
 
+// Phase clocks of the edge and variance kernels (build with -DEBO_EDGE_TIMING,
+// tools/edge_phase_clock.py, tools/eval_phase_clock.py): every wave keeps the shader-clock cycles
+// between two barrier-separated points in scalar accumulators; thread 0 of the workgroup adds
+// them to a device table when the unit is done (64 rows by workgroup index: same-address atomics
+// from every workgroup at every phase would dominate what is being measured).  Never compiled
+// into the shipped library.
+#ifdef EBO_EDGE_TIMING
+__device__ unsigned long long g_edge_clk[64 * 32];
+#define EDGE_TICK_DECL                       \
+	unsigned long long edgeClk_ = clock64(); \
+	unsigned long long edgeAcc_[24] = {0}
+#define EDGE_TICK(k)                                  \
+	do                                                \
+	{                                                 \
+		const unsigned long long now_ = clock64();    \
+		edgeAcc_[k] += now_ - edgeClk_;               \
+		edgeClk_ = now_;                              \
+	} while (0)
+#define EDGE_COUNT(k, v) edgeAcc_[k] += static_cast<unsigned long long>(v)
+#define EDGE_TICK_FLUSH                                                                       \
+	do                                                                                        \
+	{                                                                                         \
+		if (threadIdx.x == 0)                                                                 \
+		{                                                                                     \
+			for (int k_ = 0; k_ < 24; ++k_)                                                   \
+			{                                                                                 \
+				if (edgeAcc_[k_])                                                             \
+				{                                                                             \
+					atomicAdd(&g_edge_clk[(blockIdx.x & 63) * 32 + k_], edgeAcc_[k_]);        \
+				}                                                                             \
+			}                                                                                 \
+		}                                                                                     \
+	} while (0)
+#define EDGE_TICK_ARG , unsigned long long &edgeClk_, unsigned long long(&edgeAcc_)[24]
+#define EDGE_TICK_PASS , edgeClk_, edgeAcc_
+#else
+#define EDGE_TICK(k) do { } while (0)
+#define EDGE_TICK_DECL do { } while (0)
+#define EDGE_COUNT(k, v) do { } while (0)
+#define EDGE_TICK_FLUSH do { } while (0)
+#define EDGE_TICK_ARG
+#define EDGE_TICK_PASS
+#endif
+
 __device__ __forceinline__ bool convertible(double c)
 {
 	return fabs(c) < 1073741824.0;  // int(double) is defined; same guard as the CPU path
@@ -3524,21 +3568,36 @@ int launch_patch_integrate(const PatchIntLaunch& L, void* stream)
 }  // namespace ebo
 
 #ifdef EBO_EDGE_TIMING
-// Phase clocks of the edge kernel (instrumented build only; see ebo_edge.inc).
-extern "C" int ebo_debug_edge_clocks(unsigned long long* out16, int reset)
+// Phase clocks (instrumented build only): the 64 rows of the device table summed into out32.
+extern "C" int ebo_debug_edge_clocks(unsigned long long* out32, int reset)
 {
+	static unsigned long long rows[64 * 32];
 	if (hipDeviceSynchronize() != hipSuccess)
 	{
 		return -1;
 	}
-	if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(ebo::g_edge_clk), 16 * sizeof(unsigned long long)) != hipSuccess)
+	if (out32)
 	{
-		return -1;
+		if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(ebo::g_edge_clk), sizeof(rows)) != hipSuccess)
+		{
+			return -1;
+		}
+		for (int k = 0; k < 32; ++k)
+		{
+			out32[k] = 0;
+			for (int r = 0; r < 64; ++r)
+			{
+				out32[k] += rows[r * 32 + k];
+			}
+		}
 	}
 	if (reset)
 	{
-		unsigned long long zero[16] = {0};
-		if (hipMemcpyToSymbol(HIP_SYMBOL(ebo::g_edge_clk), zero, sizeof(zero)) != hipSuccess)
+		for (auto& v : rows)
+		{
+			v = 0;
+		}
+		if (hipMemcpyToSymbol(HIP_SYMBOL(ebo::g_edge_clk), rows, sizeof(rows)) != hipSuccess)
 		{
 			return -1;
 		}
