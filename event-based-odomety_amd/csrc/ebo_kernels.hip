@@ -1715,19 +1715,19 @@ __global__ void __launch_bounds__(1024) k_count_units(
 // anything huge or NaN: comparisons false) takes the f64 expression in the reference's order.
 template <bool U16>
 __device__ __forceinline__ void count_hit_uniform(uint64_t rec, bool live, int dtWin, double m0, double m1, float m0f,
-												   float m1f, float scalef, double scale, int x0, int row0, int tw, int th,
-												   unsigned int* cnt)
+												   float m1f, float thrX, float thrY, float scalef, double scale, int x0,
+												   int row0, int tw, int th, unsigned int* cnt)
 {
 	int x, y, pos, dt;
 	unpack(rec, x, y, pos, dt);
 	const int dtw = dt + dtWin;
 	const float prod = static_cast<float>(dtw) * scalef;
-	const float px = prod * m0f, py = prod * m1f;
-	const float vx = static_cast<float>(x) + px, vy = static_cast<float>(y) + py;
+	const float vx = static_cast<float>(x) + prod * m0f, vy = static_cast<float>(y) + prod * m1f;
 	const float rx = rintf(vx), ry = rintf(vy);
+	// thrX / thrY: the unit's tolerance (count_unit_tolerance), wave-uniform -- the per-event form
+	// kSureBase - 4e-7 |px| - 6e-8 |vx| cost eight vector instructions of the ~30 an event takes
 	// (bitwise, not &&: no short-circuit branches)
-	const bool sure = (static_cast<int>(fabsf(vx - rx) < kSureBase - 4e-7f * fabsf(px) - 6e-8f * fabsf(vx)) &
-					   static_cast<int>(fabsf(vy - ry) < kSureBase - 4e-7f * fabsf(py) - 6e-8f * fabsf(vy))) != 0;
+	const bool sure = (static_cast<int>(fabsf(vx - rx) < thrX) & static_cast<int>(fabsf(vy - ry) < thrY)) != 0;
 	int nx = static_cast<int>(rx), ny = static_cast<int>(ry);
 	if (!sure)
 	{
@@ -1742,16 +1742,29 @@ __device__ __forceinline__ void count_hit_uniform(uint64_t rec, bool live, int d
 	if (static_cast<int>(live) & static_cast<int>(static_cast<unsigned>(cx) < static_cast<unsigned>(tw)) &
 		static_cast<int>(static_cast<unsigned>(cy) < static_cast<unsigned>(th)))
 	{
-		const int p = cy * tw + cx;
+		// cy < th, tw < 2^15: the 24-bit multiply-add (full rate; v_mul_lo_u32 is a quarter-rate instruction)
+		const unsigned int p = __umul24(static_cast<unsigned int>(cy), static_cast<unsigned int>(tw)) + static_cast<unsigned int>(cx);
 		if (U16)
 		{
-			atomicAdd(&cnt[p >> 1], 1u << ((p & 1) * 16));
+			atomicAdd(&cnt[p >> 1], 1u << ((p & 1u) * 16u));
 		}
 		else
 		{
 			atomicAdd(&cnt[p], 1u);
 		}
 	}
+}
+
+// The float pre-test's tolerance for every event of a unit, one number per axis: the float
+// position differs from the reference's f64 one by at most 4e-7 |displacement| + 6e-8 |position|
+// (count_hit_uniform), |displacement| <= max|t_ref - t| |scale| |flow| (rounding is monotonic; 1e-6
+// relative covers the float conversions of scale and flow and the float products), |position| <= the
+// sensor's extent + the displacement.  NaN / inf flow: the tolerance is NaN or -inf, no event is
+// "sure", all take the exact path.
+__device__ __forceinline__ float count_unit_tolerance(int maxDt, double scale, double m, int extent)
+{
+	const float reach = static_cast<float>(static_cast<double>(maxDt) * fabs(scale) * fabs(m)) * 1.000001f;
+	return kSureBase - 4e-7f * reach - 6e-8f * (static_cast<float>(extent) + reach + 1.0f);
 }
 
 // Unit waves over 2-D tiles (impl 5; the warped image of R2's final loop): workgroup = (tile,
@@ -1766,9 +1779,9 @@ __device__ __forceinline__ void count_hit_uniform(uint64_t rec, bool live, int d
 // selected units (headers in hdr[0, nSel)), then stored.  U16: two 16-bit counters per dword.
 template <bool U16>
 __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, const double* __restrict__ windowFlows,
-										   const int4* hdr, int nSel, int* ctl, unsigned int* cnt, int x0, int row0, int tw, int th,
+										   const int32_t* __restrict__ wmax, const int4* hdr, int nSel, int* ctl, unsigned int* cnt, int x0, int row0, int tw, int th,
 										   double* __restrict__ out /* image(row0, x0) */, int W, bool alignedImage,
-										   const EvalConsts& c)
+										   const EvalConsts& c EDGE_TICK_ARG)
 {
 	const int npx = tw * th;
 	const int nWords = U16 ? (npx + 1) >> 1 : npx;
@@ -1781,27 +1794,49 @@ __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, c
 		ctl[0] = 0;
 	}
 	__syncthreads();
+	EDGE_TICK(17);
 	const int lane = threadIdx.x & 63;
 	const float scalef = static_cast<float>(c.scale);
 	constexpr int kInFlight = 4;
 	// Software pipeline: the loads of the NEXT batch of 256 events (the same unit's, or the first
 	// of the next unit the wave picks) are in flight while the current batch is counted.
-	int4 hA = make_int4(0, 0, 0, 0);
-	uint32_t posA = 0;
-	bool haveA = false;
+	// what a wave needs of a unit, fetched when the unit is PICKED (one batch ahead of its use):
+	// header, flow (f64 and float) and the float pre-test's tolerances -- all wave-uniform
+	struct Picked
 	{
+		int4 h;
+		double m0, m1;
+		float m0f, m1f, thrX, thrY;
+	};
+	auto pick_unit = [&](Picked& q) -> bool {
 		int pick = 0;
 		if (lane == 0)
 		{
 			pick = atomicAdd(&ctl[0], 1);
 		}
-		pick = __shfl(pick, 0, 64);
-		if (pick < nSel)
+		pick = __builtin_amdgcn_readfirstlane(pick);
+		if (pick >= nSel)
 		{
-			hA = hdr[pick];
-			posA = static_cast<uint32_t>(hA.x);
-			haveA = true;
+			return false;
 		}
+		q.h = hdr[pick];
+		const int u = q.h.w;
+		q.m0 = windowFlows[2 * u];  // 16 KB per window: L1 / L2
+		q.m1 = windowFlows[2 * u + 1];
+		q.m0f = static_cast<float>(q.m0);
+		q.m1f = static_cast<float>(q.m1);
+		const int maxDt = wmax[u];
+		q.thrX = count_unit_tolerance(maxDt, c.scale, q.m0, c.image_w);
+		q.thrY = count_unit_tolerance(maxDt, c.scale, q.m1, c.image_h);
+		return true;
+	};
+	Picked A;
+	A.h = make_int4(0, 0, 0, 0);
+	uint32_t posA = 0;
+	bool haveA = pick_unit(A);
+	if (haveA)
+	{
+		posA = static_cast<uint32_t>(A.h.x);
 	}
 	uint64_t recsA[kInFlight];
 	if (haveA)
@@ -1810,28 +1845,21 @@ __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, c
 		for (int k = 0; k < kInFlight; ++k)
 		{
 			const uint32_t ek = posA + lane + k * 64;
-			recsA[k] = (ek < static_cast<uint32_t>(hA.y)) ? events[ek] : 0ull;
+			recsA[k] = (ek < static_cast<uint32_t>(A.h.y)) ? events[ek] : 0ull;
 		}
 	}
 	while (haveA)
 	{
 		// the batch after this one
-		int4 hB = hA;
+		Picked B = A;
 		uint32_t posB = posA + kInFlight * 64;
 		bool haveB = true;
-		if (posB >= static_cast<uint32_t>(hA.y))
+		if (posB >= static_cast<uint32_t>(A.h.y))
 		{
-			int pick = 0;
-			if (lane == 0)
-			{
-				pick = atomicAdd(&ctl[0], 1);
-			}
-			pick = __shfl(pick, 0, 64);
-			haveB = pick < nSel;
+			haveB = pick_unit(B);
 			if (haveB)
 			{
-				hB = hdr[pick];
-				posB = static_cast<uint32_t>(hB.x);
+				posB = static_cast<uint32_t>(B.h.x);
 			}
 		}
 		uint64_t recsB[kInFlight];
@@ -1841,23 +1869,18 @@ __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, c
 			for (int k = 0; k < kInFlight; ++k)
 			{
 				const uint32_t ek = posB + lane + k * 64;
-				recsB[k] = (ek < static_cast<uint32_t>(hB.y)) ? events[ek] : 0ull;
+				recsB[k] = (ek < static_cast<uint32_t>(B.h.y)) ? events[ek] : 0ull;
 			}
 		}
 		// count batch A
-		{
-			const int u = hA.w;
-			const double m0 = windowFlows[2 * u], m1 = windowFlows[2 * u + 1];  // 16 KB per window: L1 / L2
-			const float m0f = static_cast<float>(m0), m1f = static_cast<float>(m1);
 #pragma unroll
-			for (int k = 0; k < kInFlight; ++k)
-			{
-				count_hit_uniform<U16>(recsA[k], posA + lane + k * 64 < static_cast<uint32_t>(hA.y), hA.z, m0, m1, m0f, m1f,
-									   scalef, c.scale, x0, row0, tw, th, cnt);
-			}
+		for (int k = 0; k < kInFlight; ++k)
+		{
+			count_hit_uniform<U16>(recsA[k], posA + lane + k * 64 < static_cast<uint32_t>(A.h.y), A.h.z, A.m0, A.m1, A.m0f,
+								   A.m1f, A.thrX, A.thrY, scalef, c.scale, x0, row0, tw, th, cnt);
 		}
 		haveA = haveB;
-		hA = hB;
+		A = B;
 		posA = posB;
 #pragma unroll
 		for (int k = 0; k < kInFlight; ++k)
@@ -1865,7 +1888,9 @@ __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, c
 			recsA[k] = recsB[k];
 		}
 	}
+	EDGE_TICK(18);
 	__syncthreads();
+	EDGE_TICK(19);
 	if (U16 && !(tw & 1) && !(W & 1) && !(x0 & 1) && alignedImage)
 	{
 		// one packed dword = two pixels of one row = one 16-byte store
@@ -1887,7 +1912,9 @@ __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, c
 			out[static_cast<size_t>(r) * W + q] = static_cast<double>(v);
 		}
 	}
+	EDGE_TICK(20);
 	__syncthreads();
+	EDGE_TICK(21);
 }
 
 __global__ void __launch_bounds__(1024) k_count_tiles(
@@ -1914,6 +1941,7 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 	// behind the counters: [0] next, [1] nSel, [2] most events of a selected unit, [3] largest reach
 	// (ceil, both axes), then one 4-int header per selected unit {first event, end, dt_win, unit}: the
 	// waves walk the units from LDS, not through dependent global loads
+	EDGE_TICK_DECL;
 	int* ctl = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt) + cntBytes);
 	int4* hdr = reinterpret_cast<int4*>(ctl + 4);
 	if (threadIdx.x < 4)
@@ -1950,7 +1978,10 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 		}
 	}
 	__syncthreads();
+	EDGE_TICK(16);
 	const int nSel = ctl[1];
+	EDGE_COUNT(22, nSel);
+	EDGE_COUNT(23, 1);
 	// 16-bit counters are safe when no pixel can collect 65536 events: a pixel is within reach of at
 	// most (1 + 2 ceil(R / pw)) (1 + 2 ceil(R / ph)) patches (the grid's last patches are larger: fewer),
 	// each with at most ctl[2] events.  Otherwise (wild flows, one patch holding most of a window)
@@ -1961,7 +1992,7 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 	const bool alignedImage = (reinterpret_cast<uintptr_t>(image) & 15) == 0;
 	if (safe16)
 	{
-		tile_pass<true>(events, windowFlows, hdr, nSel, ctl, cnt, x0, row0, tw, th, out, W, alignedImage, c);
+		tile_pass<true>(events, windowFlows, wmax, hdr, nSel, ctl, cnt, x0, row0, tw, th, out, W, alignedImage, c EDGE_TICK_PASS);
 	}
 	else
 	{
@@ -1969,10 +2000,11 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 		const int hMax = max(tileH / 2, 1);
 		for (int r = 0; r < th; r += hMax)
 		{
-			tile_pass<false>(events, windowFlows, hdr, nSel, ctl, cnt, x0, row0 + r, tw, min(hMax, th - r),
-							 out + static_cast<size_t>(r) * W, W, alignedImage, c);
+			tile_pass<false>(events, windowFlows, wmax, hdr, nSel, ctl, cnt, x0, row0 + r, tw, min(hMax, th - r),
+							 out + static_cast<size_t>(r) * W, W, alignedImage, c EDGE_TICK_PASS);
 		}
 	}
+	EDGE_TICK_FLUSH;
 }
 
 // The stray unit of every window (events outside the sensor; none in a real recording) for the

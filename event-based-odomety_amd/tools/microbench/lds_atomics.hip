@@ -149,6 +149,8 @@ int main(int argc, char** argv)
 		run("rmw f64 (read+add+write) linear", k_rmw<double>, blocks, threads, nullptr);
 		run("ds_add_u64 7-lane groups", k_atomic<unsigned long long, 5>, blocks, threads, nullptr);
 		run("ds_add_u64 random base + tap", k_atomic<unsigned long long, 6>, blocks, threads, nullptr);
+		run("ds_add_u32 random base + tap", k_atomic<unsigned int, 6>, blocks, threads, nullptr);
+		run("ds_add_u32 7-lane groups", k_atomic<unsigned int, 5>, blocks, threads, nullptr);
 		run("ds_read_b64 linear", k_read<0>, blocks, threads, nullptr);
 		run("ds_read_b64 7-lane groups", k_read<5>, blocks, threads, nullptr);
 		run("ds_read_b64 random base + tap", k_read<6>, blocks, threads, nullptr);
