@@ -1781,19 +1781,22 @@ template <bool U16>
 __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, const double* __restrict__ windowFlows,
 										   const int32_t* __restrict__ wmax, const int4* hdr, int nSel, int* ctl, unsigned int* cnt, int x0, int row0, int tw, int th,
 										   double* __restrict__ out /* image(row0, x0) */, int W, bool alignedImage,
-										   const EvalConsts& c EDGE_TICK_ARG)
+										   const EvalConsts& c, bool preZeroed EDGE_TICK_ARG)
 {
 	const int npx = tw * th;
 	const int nWords = U16 ? (npx + 1) >> 1 : npx;
-	for (int i = threadIdx.x; i < nWords; i += blockDim.x)
+	if (!preZeroed)  // (the caller zeroed the counters and ctl[0] under the latency of its unit-table loads)
 	{
-		cnt[i] = 0u;
+		for (int i = threadIdx.x; i < nWords; i += blockDim.x)
+		{
+			cnt[i] = 0u;
+		}
+		if (threadIdx.x == 0)
+		{
+			ctl[0] = 0;
+		}
+		__syncthreads();
 	}
-	if (threadIdx.x == 0)
-	{
-		ctl[0] = 0;
-	}
-	__syncthreads();
 	EDGE_TICK(17);
 	const int lane = threadIdx.x & 63;
 	const float scalef = static_cast<float>(c.scale);
@@ -1944,23 +1947,18 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 	EDGE_TICK_DECL;
 	int* ctl = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt) + cntBytes);
 	int4* hdr = reinterpret_cast<int4*>(ctl + 4);
-	if (threadIdx.x < 4)
-	{
-		ctl[threadIdx.x] = 0;
-	}
-	__syncthreads();
 	const Unit* wu = units + static_cast<size_t>(w) * unitsPerWindow;
 	const int32_t* wmax = unitMaxDt + static_cast<size_t>(w) * unitsPerWindow;
 	const size_t imgSize = static_cast<size_t>(W) * c.image_h;
 	const double* windowFlows = flows + 2 * static_cast<size_t>(w) * P;
-	// which units can reach this tile (the stray unit is left to k_count_stray)
-	for (int u = threadIdx.x; u < P; u += blockDim.x)
-	{
-		const Unit un = wu[u];
+	// which units can reach this tile (the stray unit is left to k_count_stray).  The first round of
+	// unit-table loads is issued, the tile's counters are zeroed while they are in flight (a loaded
+	// memory system answers in microseconds), then the units are sorted out.
+	auto consider = [&](int u, const Unit& un, int maxDt, double f0, double f1) {
 		bool take = un.n_ev > 0;
 		// |fl(fl(dtw * scale) * m)| <= fl(fl(maxdt * |scale|) * |m|): rounding is monotonic
-		const double t = static_cast<double>(wmax[u]) * fabs(c.scale);
-		const double reachX = t * fabs(windowFlows[2 * u]) + 1.0, reachY = t * fabs(windowFlows[2 * u + 1]) + 1.0;
+		const double t = static_cast<double>(maxDt) * fabs(c.scale);
+		const double reachX = t * fabs(f0) + 1.0, reachY = t * fabs(f1) + 1.0;
 		if (take && nTiles > 1)
 		{
 			const double lox = static_cast<double>(un.rx) - reachX, hix = static_cast<double>(un.rx + un.rw - 1) + reachX;
@@ -1975,6 +1973,38 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 			atomicMax(&ctl[2], static_cast<int>(min(un.n_ev, 0x7fffffffu)));
 			const double rr = fmax(reachX, reachY);
 			atomicMax(&ctl[3], (rr < 1e6) ? static_cast<int>(ceil(rr)) : 1000000);  // NaN -> 1000000
+		}
+	};
+	{
+		const int u0 = threadIdx.x;
+		const bool have0 = u0 < P;
+		Unit un0 = {};
+		int maxDt0 = 0;
+		double f00 = 0.0, f01 = 0.0;
+		if (have0)
+		{
+			un0 = wu[u0];
+			maxDt0 = wmax[u0];
+			f00 = windowFlows[2 * u0];
+			f01 = windowFlows[2 * u0 + 1];
+		}
+		const int nWords16 = (tw * th + 1) >> 1;
+		for (int i = threadIdx.x; i < nWords16; i += blockDim.x)
+		{
+			cnt[i] = 0u;
+		}
+		if (threadIdx.x < 4)
+		{
+			ctl[threadIdx.x] = 0;
+		}
+		__syncthreads();
+		if (have0)
+		{
+			consider(u0, un0, maxDt0, f00, f01);
+		}
+		for (int u = threadIdx.x + blockDim.x; u < P; u += blockDim.x)
+		{
+			consider(u, wu[u], wmax[u], windowFlows[2 * u], windowFlows[2 * u + 1]);
 		}
 	}
 	__syncthreads();
@@ -1992,7 +2022,7 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 	const bool alignedImage = (reinterpret_cast<uintptr_t>(image) & 15) == 0;
 	if (safe16)
 	{
-		tile_pass<true>(events, windowFlows, wmax, hdr, nSel, ctl, cnt, x0, row0, tw, th, out, W, alignedImage, c EDGE_TICK_PASS);
+		tile_pass<true>(events, windowFlows, wmax, hdr, nSel, ctl, cnt, x0, row0, tw, th, out, W, alignedImage, c, true EDGE_TICK_PASS);
 	}
 	else
 	{
@@ -2001,7 +2031,7 @@ __global__ void __launch_bounds__(1024) k_count_tiles(
 		for (int r = 0; r < th; r += hMax)
 		{
 			tile_pass<false>(events, windowFlows, wmax, hdr, nSel, ctl, cnt, x0, row0 + r, tw, min(hMax, th - r),
-							 out + static_cast<size_t>(r) * W, W, alignedImage, c EDGE_TICK_PASS);
+							 out + static_cast<size_t>(r) * W, W, alignedImage, c, false EDGE_TICK_PASS);
 		}
 	}
 	EDGE_TICK_FLUSH;

@@ -25,7 +25,7 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     ctx.set_windows(ev, offsets)
-    d_flows = torch.from_numpy(gt * 0.8).to("cuda")
+    d_flows = torch.from_numpy(gt * float(os.environ.get("AB_FLOW_SCALE", "0.8"))).to("cuda")  # AB_FLOW_SCALE=0: no unit reaches a neighbouring tile
     d_img = torch.zeros((windows, cfg["image"][1], cfg["image"][0]), dtype=torch.float64, device="cuda")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ref = {}
