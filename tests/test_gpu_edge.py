@@ -228,3 +228,32 @@ def test_edge_jacobian_is_bit_reproducible(ebo, synth, config, windows):
             for _ in range(4):
                 r, J = c.eval(gt * scale)
                 assert np.array_equal(r, r0) and np.array_equal(J, J0)
+
+
+@pytest.mark.parametrize("config,windows", [(0, 8), (2, 2), (3, 2)])
+def test_edge_direction_table_equals_rederived_tensor_sums(ebo, orc, synth, monkeypatch, config, windows):
+    """A Jacobian evaluation's reverse pass reads each argmax pixel's eigenvector direction from the
+    table the eigenvalue pass wrote (global memory, EBO_EDGE_CS_MB) instead of re-deriving the
+    tensor sums: the same Jacobian to rounding, the same value bit for bit, and both within the
+    oracle's bar (zero flow included: units whose d = 0 flag their Jacobian NaN on both paths)."""
+    cfg = synth.CONFIGS[config]
+    ev, offsets, gt = synth.make_stream(config, windows)
+    got = {}
+    for mb in ("4096", "0"):
+        monkeypatch.setenv("EBO_EDGE_CS_MB", mb)
+        with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0],
+                         patch_h=cfg["patch"][1], loss=ebo.LOSS_EDGE, tv_weight=0.0, max_events=len(ev),
+                         max_windows=windows) as c:
+            c.set_windows(ev, offsets)
+            got[mb] = [c.eval(gt * s) for s in (0.0, 0.5, 1.3)]
+            if mb == "4096":
+                prm = oparams(orc, c.params)
+                sub = ev[int(offsets[0]):int(offsets[1])]
+                ro, Jo, _, _ = orc.window_eval(sub, prm, gt[0] * 0.5)
+                check_rj(got[mb][1][0][0], got[mb][1][1][0], ro, Jo)
+    for (ra, Ja), (rb, Jb) in zip(got["4096"], got["0"]):
+        assert np.array_equal(ra, rb)
+        assert np.array_equal(np.isnan(Ja), np.isnan(Jb))
+        ok = ~np.isnan(Ja)
+        scale = np.abs(Jb[ok]).max()
+        assert np.abs(Ja[ok] - Jb[ok]).max() <= 1e-11 * scale
