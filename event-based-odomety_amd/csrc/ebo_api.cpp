@@ -4,6 +4,9 @@
 // and count image comes from the HIP kernels in ebo_kernels.hip.
 #include "ebo_ctx.h"
 
+#include <atomic>
+#include <chrono>
+
 namespace ebo_host
 {
 EvalConsts make_consts(const ebo_ctx* c)
@@ -684,6 +687,10 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 // lives for ONE solve call (threads are created when the call has enough independent problems
 // and joined before it returns): no thread of this library outlives an API call, so process
 // exit, dlclose and profilers that wrap the process never meet a parked worker.
+// A round's work is tens of microseconds per thread and rounds follow each other every ~100 us, so
+// waking parked workers through a condition variable (30-50 us) was most of a round's host time
+// (64 reference-default windows: 9.7 of 17.6 ms in the LM steps): workers and the caller SPIN on an
+// atomic for EBO_HOST_SPIN_US microseconds (default 200) before they park.
 class HostPool
 {
    public:
@@ -694,6 +701,7 @@ class HostPool
 		const char* v = std::getenv("EBO_HOST_THREADS");
 		size_t want = v ? static_cast<size_t>(std::max(1, std::atoi(v))) : std::min<size_t>(hw ? hw : 1, 16);
 		want = std::min(want, std::max<size_t>(1, problems / std::max<size_t>(1, perThread)));
+		spinUs_ = static_cast<long>(env_size("EBO_HOST_SPIN_US", 200));
 		for (size_t i = 1; i < want; ++i)
 		{
 			workers_.emplace_back([this] { run(); });
@@ -719,13 +727,15 @@ class HostPool
 			chunk_ = chunk;
 			next_ = 1;  // chunk 0 is the caller's
 			chunks_ = T;
-			pending_ = T - 1;
+			pending_.store(T - 1, std::memory_order_relaxed);
 			++generation_;
+			published_.store(generation_, std::memory_order_release);
 		}
 		cv_.notify_all();
 		fn(static_cast<size_t>(0), std::min(n, chunk));
+		spin_until([&] { return pending_.load(std::memory_order_acquire) == 0; });
 		std::unique_lock<std::mutex> lk(mu_);
-		done_.wait(lk, [&] { return pending_ == 0; });
+		done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
 		job_ = nullptr;
 	}
 
@@ -736,6 +746,7 @@ class HostPool
 		{
 			std::unique_lock<std::mutex> lk(mu_);
 			stop_ = true;
+			published_.store(~static_cast<size_t>(0), std::memory_order_release);  // ends the spinning
 		}
 		cv_.notify_all();
 		for (auto& t : workers_)
@@ -744,19 +755,51 @@ class HostPool
 		}
 	}
    private:
-	void run()
+	template <class P>
+	void spin_until(P&& ready) const
 	{
-		size_t seen = 0;
+		if (spinUs_ <= 0 || ready())
+		{
+			return;
+		}
+		const auto t0 = std::chrono::steady_clock::now();
 		for (;;)
 		{
+			for (int i = 0; i < 32; ++i)
+			{
+				if (ready())
+				{
+					return;
+				}
+#if defined(__x86_64__) || defined(__i386__)
+				__builtin_ia32_pause();
+#endif
+			}
+			if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spinUs_)
+			{
+				return;
+			}
+		}
+	}
+	void run()
+	{
+		size_t seen = 0;  // the last generation this worker has nothing more to do for
+		for (;;)
+		{
+			spin_until([&] { return published_.load(std::memory_order_acquire) != seen; });
 			std::function<void(size_t, size_t)>* job = nullptr;
 			size_t b = 0, e = 0;
 			{
 				std::unique_lock<std::mutex> lk(mu_);
-				cv_.wait(lk, [&] { return stop_ || (generation_ != seen && job_ && next_ < chunks_); });
+				cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
 				if (stop_)
 				{
 					return;
+				}
+				if (!job_ || next_ >= chunks_)
+				{
+					seen = generation_;  // every chunk of this generation has been taken
+					continue;
 				}
 				const size_t k = next_++;
 				if (next_ >= chunks_)
@@ -771,9 +814,9 @@ class HostPool
 			{
 				(*job)(b, e);
 			}
-			std::unique_lock<std::mutex> lk(mu_);
-			if (--pending_ == 0)
+			if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1)
 			{
+				std::unique_lock<std::mutex> lk(mu_);
 				done_.notify_all();
 			}
 		}
@@ -782,7 +825,9 @@ class HostPool
 	std::mutex mu_;
 	std::condition_variable cv_, done_;
 	std::function<void(size_t, size_t)>* job_ = nullptr;
-	size_t n_ = 0, chunk_ = 0, next_ = 0, chunks_ = 0, pending_ = 0, generation_ = 0;
+	size_t n_ = 0, chunk_ = 0, next_ = 0, chunks_ = 0, generation_ = 0;
+	std::atomic<size_t> pending_{0}, published_{0};
+	long spinUs_ = 200;
 	bool stop_ = false;
 };
 
@@ -999,7 +1044,8 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 	std::vector<double> flows(static_cast<size_t>(Wn) * P * 2, 0.0);
 	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
 	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
-	HostPool pool(static_cast<size_t>(Wn), 8);
+	// (with spinning workers a thread pays off from two windows' LM steps up: 64 windows, 17.2 -> see DESIGN 4.3)
+	HostPool pool(static_cast<size_t>(Wn), 2);
 	// EBO_SOLVE_TRACE=1: where a lock-step solve spends its time (stderr, one line per call)
 	const bool trace = std::getenv("EBO_SOLVE_TRACE") != nullptr;
 	double tReq = 0.0, tEval = 0.0, tSup = 0.0;
@@ -1092,7 +1138,7 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 					break;
 				}
 				const auto t2 = now();
-				pool.parallel_for(wSplit[g + 1] - wSplit[g], 8, [&](size_t b, size_t e) {
+				pool.parallel_for(wSplit[g + 1] - wSplit[g], 2, [&](size_t b, size_t e) {
 					for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
 					{
 						if (wmode[w] != 0)
@@ -1155,7 +1201,7 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 			return rc;
 		}
 		const auto t2 = now();
-		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
+		pool.parallel_for(static_cast<size_t>(Wn), 2, [&](size_t b, size_t e) {
 			for (size_t w = b; w < e; ++w)
 			{
 				if (wmode[w] != 0)
