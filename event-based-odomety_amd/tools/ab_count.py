@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 ebo = importlib.import_module("event-based-odomety_amd")
 synth = importlib.import_module("event-based-odomety_amd.synth")
+if os.environ.get("AB_LIB"):  # A/B of two builds on the same box
+    ebo.LIB_PATH = os.path.join(os.path.dirname(ebo.LIB_PATH), os.environ["AB_LIB"])
 
 KEYS = ("EBO_COUNT_IMPL", "EBO_COUNT_LDS_KB", "EBO_COUNT_BLOCK")
 
