@@ -91,6 +91,8 @@ __device__ __forceinline__ bool convertible(double c)
 // quad neighbours, the other pair of the quad, 4 and 8 lanes down the row of 16, then lane 15 of
 // the previous row into rows 1 and 3 and lane 31 into rows 2 and 3.  A lane with no source gets
 // `idle` (the operation's identity).  The wave's result is in LANE 63 (kWaveResultLane).
+// Whole waves only: every launch site of a kernel that reduces uses a workgroup size that is a
+// multiple of 64 (the environment overrides are validated), so lane 63 of every wave exists.
 constexpr int kWaveResultLane = 63;
 
 template <int CTRL, int ROW_MASK>
