@@ -200,7 +200,11 @@ int ebo_patch_info(const ebo_ctx* ctx, int window, int patch, int32_t* n_events,
 
 /* R1, batched over every patch of every loaded window: residual r and (if jac
  * != NULL) the 1x2 Jacobian at flows[w][p][0..1].  Inactive patches give 0.
- * Host pointers: flows [Wn][P][2], r [Wn][P], jac [Wn][P][2]. Synchronous. */
+ * Host pointers: flows [Wn][P][2], r [Wn][P], jac [Wn][P][2]. Synchronous.
+ * Device memory: with EBO_LOSS_EDGE a Jacobian evaluation keeps a work table of 16 bytes per
+ * LDS-resident canvas pixel and patch (reference defaults: 57.6 KB per patch; allocated on first
+ * use, grown on demand, freed by ebo_destroy); above 4 GiB it is not used and the kernel re-derives
+ * what it held (environment EBO_EDGE_CS_MB). */
 int ebo_eval(ebo_ctx* ctx, const double* flows, double* r, double* jac);
 /* Same on device pointers, asynchronous on the context's stream:
  * d_flows [Wn][P][2], d_out [Wn][P][3] = (r, J0, J1). */
