@@ -1092,7 +1092,8 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 		bool inflight[kMaxGroups] = {false, false, false, false}, gJac[kMaxGroups] = {false, false, false, false};
 		// request: every window of the half says what it wants next; true if any is still running
 		auto request = [&](int g) {
-			pool.parallel_for(wSplit[g + 1] - wSplit[g], 8, [&](size_t b, size_t e) {
+			// (a request is a copy of 2 P doubles and a memset: threads only from 64 windows per thread up)
+			pool.parallel_for(wSplit[g + 1] - wSplit[g], 64, [&](size_t b, size_t e) {
 				for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
 				{
 					const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
@@ -1122,6 +1123,8 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 			}
 		}
 		auto anyInflight = [&] { for (int g = 0; g < G; ++g) { if (inflight[g]) return true; } return false; };
+		std::vector<size_t> live;
+		live.reserve(static_cast<size_t>(Wn));
 		while (rc == EBO_OK && anyInflight())
 		{
 			for (int g = 0; g < G && rc == EBO_OK; ++g)
@@ -1138,13 +1141,21 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 					break;
 				}
 				const auto t2 = now();
-				pool.parallel_for(wSplit[g + 1] - wSplit[g], 2, [&](size_t b, size_t e) {
-					for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
+				// the windows of the half that are still running (late in a solve: a few stragglers, which
+				// then do not pay for waking the pool)
+				live.clear();
+				for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
+				{
+					if (wmode[w] != 0)
 					{
-						if (wmode[w] != 0)
-						{
-							lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
-						}
+						live.push_back(w);
+					}
+				}
+				pool.parallel_for(live.size(), 2, [&](size_t b, size_t e) {
+					for (size_t k = b; k < e; ++k)
+					{
+						const size_t w = live[k];
+						lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
 					}
 				});
 				const auto t3 = now();
