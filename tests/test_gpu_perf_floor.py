@@ -60,3 +60,34 @@ def test_hot_kernels_run_at_device_speed(ebo, synth):
         assert tbs >= 1.0, tbs
         assert tbw >= 0.8, tbw
         assert gset >= 1.5, gset
+
+
+def test_edge_loss_kernel_runs_at_device_speed(ebo, synth):
+    """The reference's active loss on its default configuration (240x180, 20x20 patches, 15 k events per
+    window), 64 windows per launch: value + Jacobian at >= 0.8 Gevents/s (measured 2.1-2.4: 0.40 ms),
+    value only at >= 1.5 (measured 4.3)."""
+    n_windows = 64
+    ev, offsets, gt = synth.make_stream(0, n_windows)
+    with ebo.Context(image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE, tv_weight=0.0,
+                     max_events=len(ev), max_windows=n_windows) as c:
+        stream = torch.cuda.current_stream()
+        c.set_stream(stream.cuda_stream)
+        c.set_windows(ev, offsets)
+        d_flows = torch.from_numpy(gt * 0.5).to("cuda")
+        d_out = torch.zeros((n_windows * c.P, 3), dtype=torch.float64, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rates = []
+        for jac in (1, 0):
+            for _ in range(5):
+                c.eval_device(d_flows.data_ptr(), jac, d_out.data_ptr())
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(20):
+                c.eval_device(d_flows.data_ptr(), jac, d_out.data_ptr())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            rates.append(len(ev) / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9)
+        print("edge loss: %.2f Gevents/s with Jacobian, %.2f value only" % tuple(rates))
+        assert np.isfinite(d_out.cpu().numpy()).all()
+        assert rates[0] >= 0.8, rates
+        assert rates[1] >= 1.5, rates
