@@ -194,7 +194,8 @@ struct BucketLaunch
 	const unsigned long long* d_offsets; // [n_windows + 1], absolute indices into d_raw
 	int n_windows;
 	int P;
-	int max_chunks;                    // ceil(max events per window / 2048)
+	int chunk_events;                  // events per chunk of the count / scatter passes: 2048, or 256 for small inputs
+	int max_chunks;                    // ceil(max events per window / chunk_events)
 	unsigned int min_events;
 	int* d_cnt;                        // [n_windows][P+1] scratch (counts)
 	unsigned int* d_chunk_hist;        // [n_windows][max_chunks][P+1]: per-chunk histograms, then the chunks' first ranks

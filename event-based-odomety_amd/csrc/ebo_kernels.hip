@@ -3174,7 +3174,7 @@ static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 			return -2;
 		}
 		hipLaunchKernelGGL(k_bucket_count<Rec>, dim3(L.max_chunks, nw), dim3(256), lds, s, raw,
-						   L.d_offsets, w0, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.d_chunk_hist, L.c);
+						   L.d_offsets, w0, L.P, L.d_cnt, L.d_tmin, L.d_tmax, L.d_flag, L.d_chunk_hist, L.chunk_events, L.c);
 		if (check_launch())
 		{
 			return -2;
@@ -3190,7 +3190,7 @@ static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 	if (L.max_chunks > 0)
 	{
 		hipLaunchKernelGGL(k_bucket_chunk_scan, dim3((L.P + 1 + 255) / 256, nw), dim3(256), 0, s, L.d_offsets, w0, L.P,
-						   L.max_chunks, L.d_chunk_hist);
+						   L.max_chunks, L.chunk_events, L.d_chunk_hist);
 		if (check_launch())
 		{
 			return -2;
@@ -3202,7 +3202,7 @@ static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 		}
 		hipLaunchKernelGGL(k_bucket_scatter<Rec>, dim3(L.max_chunks, nw), dim3(64), curLds, s, raw,
 						   L.d_offsets, w0, L.P, L.d_chunk_hist, L.d_units, L.d_unit_tref, L.d_win_tref, L.d_packed,
-						   L.d_flag, L.c);
+						   L.d_flag, L.chunk_events, L.c);
 		if (check_launch())
 		{
 			return -2;

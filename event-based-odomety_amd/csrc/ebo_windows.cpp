@@ -68,7 +68,10 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	L.d_tbase = reinterpret_cast<long long*>(base + bOff + bCnt + 3 * bT + bW + 256);
 	L.n_windows = n_windows;
 	L.P = P;
-	L.max_chunks = static_cast<int>((maxWin + 2047) / 2048);
+	// small inputs (one window of the reference configuration is 15 k events) get 256-event chunks: the
+	// scatter is one WAVE per chunk, and eight waves are not a launch
+	L.chunk_events = (offsets[n_windows] - offsets[0]) <= (static_cast<size_t>(1) << 19) ? 256 : 2048;
+	L.max_chunks = static_cast<int>((maxWin + L.chunk_events - 1) / L.chunk_events);
 	{
 		// [windows][chunks][P + 1] counters of the stable scatter: events x (P + 1) / 512 bytes
 		const size_t needHist = static_cast<size_t>(n_windows) * std::max(L.max_chunks, 1) * (P + 1);
