@@ -154,14 +154,14 @@ def cpu_baseline_all_cores(cfg_idx, seconds):
 # --------------------------------------------------------------------------------------------
 # launcher
 # --------------------------------------------------------------------------------------------
-LDS_PEAK_GOPS = {"ds_add_u64_random": 3479.0, "ds_read_b64_linear": 7617.0}  # measured, MI355X, 4 workgroups per CU
+LDS_PEAK_GOPS = {"ds_add_u64_random": 3479.0, "ds_read_b64_random": 5741.0}  # measured, MI355X, 4 workgroups per CU
 
 
 def lds_roofline(event_evals, kern_ms):
     """The LDS-side bound of one value+Jacobian evaluation launch: time the scatter's atomics and the
     gather's reads would take at the microbenchmarked LDS rates, against the measured launch."""
     min_ms = (49.0 * event_evals / (LDS_PEAK_GOPS["ds_add_u64_random"] * 1e9)
-              + 49.0 * event_evals / (LDS_PEAK_GOPS["ds_read_b64_linear"] * 1e9)) * 1e3
+              + 49.0 * event_evals / (LDS_PEAK_GOPS["ds_read_b64_random"] * 1e9)) * 1e3
     return {"ops_per_event": {"ds_add_u64": 49, "ds_read_b64": 49}, "peak_Gops": LDS_PEAK_GOPS,
             "min_ms": min_ms, "frac": min_ms / kern_ms, "source": "event-based-odomety_amd/tools/microbench/lds_atomics.hip"}
 
@@ -736,7 +736,7 @@ def main():
                                  "atomics + f64 VALU, not HBM (DESIGN.md section 4)",
                          # what does bind it: 49 64-bit LDS atomics + 49 64-bit LDS reads per event-evaluation
                          # against the chip-wide rates of tools/microbench/lds_atomics.hip on this GPU
-                         # (ds_add_u64 at random addresses, ds_read_b64 linear)
+                         # (ds_add_u64 and ds_read_b64 at random addresses)
                          "lds": lds_roofline(units_per_step, kern_ms) if workload != "c4" else None},
             "cpu_baseline": base,
             "extras": extras,

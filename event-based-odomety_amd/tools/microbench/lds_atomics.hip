@@ -66,6 +66,7 @@ __global__ void k_read(double* out, int iters)
 	{
 		unsigned a;
 		if (PATTERN == 0) a = (threadIdx.x + it * 64) & (LDS_ELEMS - 1);
+		else if (PATTERN == 1) { rnd = rnd * 1664525u + 1013904223u; a = (rnd >> 10) & (LDS_ELEMS - 1); }
 		else if (PATTERN == 5)
 		{
 			const unsigned g = (threadIdx.x & 63) / 7 + (threadIdx.x >> 6) * 9;
@@ -152,6 +153,7 @@ int main(int argc, char** argv)
 		run("ds_add_u32 random base + tap", k_atomic<unsigned int, 6>, blocks, threads, nullptr);
 		run("ds_add_u32 7-lane groups", k_atomic<unsigned int, 5>, blocks, threads, nullptr);
 		run("ds_read_b64 linear", k_read<0>, blocks, threads, nullptr);
+		run("ds_read_b64 random", k_read<1>, blocks, threads, nullptr);
 		run("ds_read_b64 7-lane groups", k_read<5>, blocks, threads, nullptr);
 		run("ds_read_b64 random base + tap", k_read<6>, blocks, threads, nullptr);
 	}
