@@ -4,11 +4,13 @@
 // the MI355X through the C ABI.
 //
 // Three ways in, from "unchanged caller" to "fast":
-//  1. tracker::contrastFunctor(events, patchRect, compensateScale) — same constructor; call
-//     operator()(motion, residual) (the T=double instantiation) or
-//     Evaluate(parameters, residuals, jacobians) (what AutoDiffCostFunction<contrastFunctor,1,2>
-//     exposes to Ceres: 1 parameter block of 2, 1 residual, Jacobian 1x2 row-major,
-//     jacobians == nullptr or jacobians[0] == nullptr => value only).  One device launch per call.
+//  1. tracker::contrastFunctor(events, patchRect, compensateScale) — same constructor and the
+//     reference's templated operator()(const T* motion, T* residual): T = double AND T = ceres::Jet,
+//     so ceres::AutoDiffCostFunction<tracker::contrastFunctor,1,2> is built by the reference's own
+//     statement (feature_detector.cpp:359-363) with no edit.  Evaluate(parameters, residuals,
+//     jacobians) is the same call without Jets (1 parameter block of 2, 1 residual, Jacobian 1x2
+//     row-major, jacobians == nullptr or jacobians[0] == nullptr => value only).  One device launch
+//     per call and block (tests/cpp/ceres_reference_lines_test.cpp).
 //  2. tracker::ContrastBatch — all patches of a problem in one context; evaluate(flows) is ONE
 //     launch for every patch; HipContrastCost blocks read the cached results.
 //  3. With Ceres present: HipContrastCost is a ceres::SizedCostFunction<1,2> and
@@ -178,6 +180,30 @@ struct contrastFunctor
 			return false;
 		}
 		residual[0] = batch_->residual(0);
+		return true;
+	}
+
+	// T = ceres::Jet<double, N> instantiation (any type with a scalar part `.a` and Jet algebra):
+	// what `new ceres::AutoDiffCostFunction<tracker::contrastFunctor, 1, 2>(new
+	// tracker::contrastFunctor(patchEvents, patchRect, compensateScale))` -- the reference's own line,
+	// feature_detector.cpp:359-363 -- instantiates, so that line compiles and runs UNCHANGED.  The
+	// device evaluates the residual and its 1x2 Jacobian at (motion[0].a, motion[1].a) in one launch
+	// (the same arithmetic the reference's Jet<double,2> carries through compensateEvents and the
+	// loss); the partials follow by the chain rule AutoDiff expects,
+	//     residual.a = r,   residual.v = J0 * motion[0].v + J1 * motion[1].v,
+	// written in Jet algebra only (Jet * double, Jet + Jet), so Ceres' Eigen-backed Jet and any
+	// other dual-number type work alike.
+	template <typename T>
+	bool operator()(const T* motion, T* residual) const
+	{
+		const double point[2] = {static_cast<double>(motion[0].a), static_cast<double>(motion[1].a)};
+		if (!batch_->evaluate(point, true))
+		{
+			return false;
+		}
+		T out = motion[0] * batch_->jacobian(0)[0] + motion[1] * batch_->jacobian(0)[1];
+		out.a = batch_->residual(0);
+		residual[0] = out;
 		return true;
 	}
 

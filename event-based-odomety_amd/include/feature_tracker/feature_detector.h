@@ -90,6 +90,15 @@ struct DetectorParams
 	int loss = EBO_LOSS_EDGE;       // reference default; EBO_LOSS_VARIANCE = north-star objective
 	int grad = EBO_GRAD_JET;        // reference default (ceres::Jet)
 	int solveMode = EBO_SOLVE_GLOBAL;  // reference default: one problem incl. TV terms
+	// The reference never throws on this path.  ERRORS_THROW (default: a missing GPU or a failed
+	// launch must not go unnoticed) raises std::runtime_error; ERRORS_STATUS never throws: a failed
+	// call leaves its outputs as they were and is reported by status() / lastError() / ok().
+	enum ErrorPolicy
+	{
+		ERRORS_THROW = 0,
+		ERRORS_STATUS = 1
+	};
+	int errorPolicy = ERRORS_THROW;
 };
 
 class FeatureDetector
@@ -115,16 +124,28 @@ class FeatureDetector
 		const int rc = ebo_create(&p, &ctx_);
 		if (rc != EBO_OK)
 		{
-			throw std::runtime_error(std::string("tracker::FeatureDetector: ") + ebo_last_error(nullptr));
+			ctx_ = nullptr;
+			fail(rc, ebo_last_error(nullptr));
+			numPatchesX_ = p.patch_w > 0 ? p.image_w / p.patch_w : 0;
+			numPatchesY_ = p.patch_h > 0 ? p.image_h / p.patch_h : 0;
 		}
-		ebo_grid(ctx_, &numPatchesX_, &numPatchesY_);
+		else
+		{
+			ebo_grid(ctx_, &numPatchesX_, &numPatchesY_);
+		}
 		compensatedEventImage_ = Mat64(p.image_h, p.image_w);
 		integratedEventImage_ = Mat64(p.image_h, p.image_w);
 		motionField_.assign(static_cast<size_t>(p.image_h) * p.image_w * 2, 0.0f);
 		patchFlows_.assign(static_cast<size_t>(numPatchesX_) * numPatchesY_ * 2, 0.0);
 		lastCompensation = common::timestamp_t(0);
 	}
-	~FeatureDetector() { ebo_destroy(ctx_); }
+	~FeatureDetector()
+	{
+		if (ctx_)
+		{
+			ebo_destroy(ctx_);
+		}
+	}
 	FeatureDetector(const FeatureDetector&) = delete;
 	FeatureDetector& operator=(const FeatureDetector&) = delete;
 
@@ -153,8 +174,11 @@ class FeatureDetector
 		ebo_solver_opts o;
 		ebo_default_solver(&o);
 		o.mode = params_.solveMode;
-		check(ebo_compensate_events_contrast(ctx_, ev.data(), ev.size(), &o, patchFlows_.data(),
-											 compensatedEventImage_.ptr(), &lastSummary_));
+		if (!check(ebo_compensate_events_contrast(ctx_, ev.data(), ev.size(), &o, patchFlows_.data(),
+												  compensatedEventImage_.ptr(), &lastSummary_)))
+		{
+			return;
+		}
 		// :418-431 the reference stores the flows at the patch corners of its motion field
 		for (int y = 0; y < numPatchesY_; ++y)
 		{
@@ -178,8 +202,10 @@ class FeatureDetector
 			integratedEventImage_ = Mat64(params_.imageSize.height, params_.imageSize.width);
 			return;
 		}
-		check(ebo_set_window(ctx_, ev.data(), ev.size()));
-		check(ebo_count_image(ctx_, EBO_COUNT_INTEGRATED, nullptr, integratedEventImage_.ptr()));
+		if (check(ebo_set_window(ctx_, ev.data(), ev.size())))
+		{
+			check(ebo_count_image(ctx_, EBO_COUNT_INTEGRATED, nullptr, integratedEventImage_.ptr()));
+		}
 	}
 
 	// feature_detector.cpp:243-296.  With patch trajectories installed (setPatchTrajectories)
@@ -207,8 +233,10 @@ class FeatureDetector
 			}
 		}
 		const std::vector<ebo_event> ev = common::toEboEvents(events);
-		check(ebo_set_window(ctx_, ev.data(), ev.size()));
-		check(ebo_count_image(ctx_, EBO_COUNT_FIELD, motionField_.data(), compensatedEventImage_.ptr()));
+		if (check(ebo_set_window(ctx_, ev.data(), ev.size())))
+		{
+			check(ebo_count_image(ctx_, EBO_COUNT_FIELD, motionField_.data(), compensatedEventImage_.ptr()));
+		}
 	}
 
 	// feature_detector.cpp:53-142.  The reference reads the trajectories of its tracked
@@ -242,6 +270,10 @@ class FeatureDetector
 	void interpolateMotionField(const common::timestamp_t timestamp)
 	{
 		initMotionField(timestamp);
+		if (status_ != EBO_OK)
+		{
+			return;
+		}
 		check(ebo_interpolate_motion_field(ctx_, params_.useL1 ? 1 : 0, nullptr, motionField_.data(),
 										   &lastFieldSummary_, nullptr));
 	}
@@ -252,8 +284,14 @@ class FeatureDetector
 	{
 		if (field.size() != motionField_.size())
 		{
-			throw std::invalid_argument("motion field must be height*width*2 floats");
+			if (params_.errorPolicy == DetectorParams::ERRORS_THROW)
+			{
+				throw std::invalid_argument("motion field must be height*width*2 floats");
+			}
+			fail(EBO_ERR_ARG, "motion field must be height*width*2 floats");
+			return;
 		}
+		status_ = EBO_OK;
 		motionField_ = field;
 	}
 	const std::vector<float>& getMotionField() const { return motionField_; }
@@ -271,14 +309,40 @@ class FeatureDetector
 	void setParams(const DetectorParams& params) { params_.maxNumEventsToStore = params.maxNumEventsToStore; }
 	ebo_ctx* handle() { return ctx_; }
 
+	// DetectorParams::ERRORS_STATUS: the EBO_* code and message of the LAST call (EBO_OK / "" after
+	// a call that succeeded).
+	int status() const { return status_; }
+	bool ok() const { return status_ == EBO_OK; }
+	const std::string& lastError() const { return lastError_; }
+
    private:
-	void check(int rc)
+	bool check(int rc)
 	{
+		if (ctx_ == nullptr)
+		{
+			fail(EBO_ERR_NO_DEVICE, "no device context (construction failed)");
+			return false;
+		}
 		if (rc != EBO_OK)
 		{
-			throw std::runtime_error(std::string("tracker::FeatureDetector: ") + ebo_last_error(ctx_));
+			fail(rc, ebo_last_error(ctx_));
+			return false;
+		}
+		status_ = EBO_OK;
+		lastError_.clear();
+		return true;
+	}
+	void fail(int rc, const char* what)
+	{
+		status_ = rc;
+		lastError_ = std::string("tracker::FeatureDetector: ") + (what ? what : "");
+		if (params_.errorPolicy == DetectorParams::ERRORS_THROW)
+		{
+			throw std::runtime_error(lastError_);
 		}
 	}
+	int status_ = EBO_OK;
+	std::string lastError_;
 
 	DetectorParams params_;
 	ebo_summary lastFieldSummary_{};

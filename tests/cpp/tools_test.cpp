@@ -128,6 +128,39 @@ int main(int argc, char** argv)
 			EXPECT_TRUE(static_cast<int>(id) == trajectories[i].first);
 		}
 	}
+	// Error policy of the facade (the reference never throws on this path): a device ordinal that
+	// does not exist fails ebo_create on any box.  ERRORS_THROW (default) raises; ERRORS_STATUS
+	// reports through status() / lastError() and every later call is a recorded no-op.
+	{
+		tracker::DetectorParams dp;
+		dp.device = 9999;
+		bool threw = false;
+		try
+		{
+			tracker::FeatureDetector detector(dp);
+		}
+		catch (const std::runtime_error& e)
+		{
+			threw = std::string(e.what()).find("tracker::FeatureDetector") == 0;
+		}
+		EXPECT_TRUE(threw);
+		dp.errorPolicy = tracker::DetectorParams::ERRORS_STATUS;
+		tracker::FeatureDetector quiet(dp);
+		EXPECT_TRUE(!quiet.ok() && quiet.status() != EBO_OK && !quiet.lastError().empty());
+		EXPECT_TRUE(quiet.numPatchesX() == 12 && quiet.numPatchesY() == 9);
+		common::EventSample e;
+		e.value.point = {5, 5};
+		e.value.sign = common::EventPolarity::POSITIVE;
+		e.timestamp = common::timestamp_t(10);
+		quiet.addEvent(e);
+		quiet.compensateEventsContrast(quiet.getEvents());  // must not throw, must not crash
+		EXPECT_TRUE(quiet.status() == EBO_ERR_NO_DEVICE);
+		quiet.integrateEvents(quiet.getEvents());
+		EXPECT_TRUE(!quiet.ok());
+		EXPECT_TRUE(quiet.getCompensatedEventImage().rows == 180 && quiet.getCompensatedEventImage().at<double>(5, 5) == 0.0);
+		quiet.setMotionField(std::vector<float>(3));  // wrong size: recorded, not thrown
+		EXPECT_TRUE(quiet.status() == EBO_ERR_ARG);
+	}
 	std::printf(g_fail ? "tools_test: %d FAILED\n" : "tools_test: all passed\n", g_fail);
 	return g_fail ? 1 : 0;
 }

@@ -49,6 +49,32 @@ def test_ceres_surface_solves_like_ebo_solve(ebo):
     assert "all passed" in out.stdout
 
 
+def test_reference_construction_lines_compile(ebo):
+    """CPU: the reference's own statements -- `new ceres::AutoDiffCostFunction<tracker::contrastFunctor, 1,
+    2>(new tracker::contrastFunctor(patchEvents, patchRect, params_.compensateScale))`, the
+    AutoDiffCostFunction<tracker::totalVarianceFunctor, 2, 2, 2> + HuberLoss blocks and Solve
+    (feature_detector.cpp:357-414) -- compile under -Wall -Wextra against the facade (reference-style
+    <feature_tracker/...> includes): the functor's operator() is instantiated with ceres::Jet."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "ceres_reference_lines_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_reference_construction_lines_solve_like_ebo_solve(ebo):
+    """The problem built by those unchanged statements, every data term evaluated through
+    AutoDiffCostFunction<contrastFunctor,1,2>::Evaluate -> operator()<Jet<double,2>> -> one device launch,
+    minimised by the product's host LM behind ceres::Solve: the flows of ebo_solve(EBO_SOLVE_GLOBAL) bit
+    for bit, both losses; the Jet path equals Evaluate() and obeys the chain rule for a general seed."""
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "ceres_reference_lines_test"])
+    out = subprocess.run([os.path.join(CPP, "ceres_reference_lines_test")], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "all passed" in out.stdout
+
+
 def test_reference_replayer_and_trajectory_scenarios(ebo):
     """CPU: tools/replayer/test/replayer_test.cpp:67-125 (nextTest, nextImageTest, resetTest on the
     reference's own two data files) through tools::StreamPump, and
