@@ -17,7 +17,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libebo_hip.so")
+# EBO_LIB_PATH: another build of the same library (tools/ A/B runs of two builds on one box only)
+LIB_PATH = os.environ.get("EBO_LIB_PATH") or os.path.join(HERE, "libebo_hip.so")
 HEADER_PATH = os.path.join(ROOT, "include", "ebo.h")
 
 OK = 0
@@ -178,6 +179,15 @@ def optimizer_default_solver(**kw):
             raise AttributeError(key)
         setattr(o, key, val)
     return o
+
+
+def window_ref_time(t_first_us, t_last_us):
+    """The reference time of a window from its first / last event time (feature_detector.cpp:305-306)."""
+    out = C.c_int64()
+    rc = lib().ebo_window_ref_time(C.c_int64(int(t_first_us)), C.c_int64(int(t_last_us)), C.byref(out))
+    if rc:
+        raise EboError(rc, "window mid-time outside int32 microseconds")
+    return out.value
 
 
 def shard_range(n_units, rank, world):
@@ -432,6 +442,21 @@ class Context:
         self._check(lib().ebo_count_image(self._h, int(mode), a, _dp(img)))
         return img
 
+    def count_image_shard(self, n_windows, t_ref_us, flows_grid):
+        """Partial final image (this context's events only) of n_windows windows whose patches are
+        sharded: flows_grid [n_windows][P][2] = flows of ALL grid patches, t_ref_us [n_windows] = the
+        windows' reference times.  Needs set_patches."""
+        t_ref = np.ascontiguousarray(t_ref_us, dtype=np.int64).reshape(n_windows)
+        flows = np.ascontiguousarray(flows_grid, dtype=np.float64).reshape(n_windows, self.P, 2)
+        img = np.zeros((n_windows, self.params.image_h, self.params.image_w))
+        self._check(lib().ebo_count_image_shard(self._h, int(n_windows), _vp(t_ref), _dp(flows), _dp(img)))
+        return img
+
+    def count_image_shard_device(self, n_windows, t_ref_us, d_flows_grid, d_image):
+        t_ref = np.ascontiguousarray(t_ref_us, dtype=np.int64).reshape(n_windows)
+        self._check(lib().ebo_count_image_shard_device(self._h, int(n_windows), _vp(t_ref),
+                                                       C.c_void_p(int(d_flows_grid)), C.c_void_p(int(d_image))))
+
     def count_image_device(self, mode, d_aux, d_image):
         self._check(lib().ebo_count_image_device(
             self._h, int(mode), C.c_void_p(int(d_aux)) if d_aux else None,
@@ -594,19 +619,28 @@ class Context:
         self._check(lib().ebo_allgather_device(
             self._h, C.c_void_p(int(d_send)), C.c_void_p(int(d_recv)), C.c_size_t(int(count_per_rank))))
 
+    def comm_size(self):
+        """(rank, nranks) of the context's communicator; (0, 1) without one."""
+        r, n = C.c_int(), C.c_int()
+        self._check(lib().ebo_comm_size(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def reduce_sum_device(self, d_send, d_recv, count, root=-1):
+        """Sum of `count` doubles over the ranks into d_recv on `root` (every rank when root < 0)."""
+        self._check(lib().ebo_reduce_sum_device(
+            self._h, C.c_void_p(int(d_send)), C.c_void_p(int(d_recv)) if d_recv else None, C.c_size_t(int(count)),
+            int(root)))
+
     def allgather_tracks(self, local):
-        """Every rank's track records on every rank (rank order): -> (records, counts per rank)."""
+        """Every rank's track records on every rank (rank order): -> (records, counts per rank).  The counts
+        collective sizes the result (its array from the communicator's own size), the gather fills it."""
         local = np.ascontiguousarray(local, dtype=TRACK_DTYPE)
         nr = C.c_size_t()
-        counts = np.zeros(max(getattr(self, "_nranks", 1), 1), dtype=np.uint64)
-        rc = lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), None, C.c_size_t(0),
-                                        C.byref(nr), _vp(counts))
-        if rc and not (rc == ERR_ARG and nr.value > 0):
-            self._check(rc)
+        counts = np.zeros(self.comm_size()[1], dtype=np.uint64)
+        self._check(lib().ebo_allgather_track_counts(self._h, C.c_size_t(len(local)), C.byref(nr), _vp(counts)))
         out = np.zeros(nr.value, dtype=TRACK_DTYPE)
-        if nr.value:
-            self._check(lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), _vp(out),
-                                                   C.c_size_t(len(out)), C.byref(nr), _vp(counts)))
+        self._check(lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), _vp(out) if len(out) else None,
+                                               C.c_size_t(len(out)), C.byref(nr), _vp(counts)))
         return out, counts.astype(np.int64)
 
     def comm_destroy(self):

@@ -268,11 +268,6 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	{
 		L.block = (L.alias_lds && headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx <= 80 * 1024 - 256) ? 512 : 1024;
 	}
-	if (L.alias_lds)
-	{
-		// the in-LDS list compaction keeps 8 counts per thread in registers
-		L.cap_px = std::min(L.cap_px, 8 * L.block);
-	}
 	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx;
 	L.scratch_stride = (canvasPx * (bytesPerPx + 1) + 256 + 255) & ~static_cast<size_t>(255);  // I, E, A, cnt + the argmax list (canvasPx / 4 + 64 ints)
 	L.d_scratch = nullptr;
@@ -1931,6 +1926,115 @@ int ebo_count_image_device(ebo_ctx* c, int mode, const void* d_aux, double* d_im
 		return c->fail(EBO_ERR_STATE, "no window loaded");
 	}
 	return count_device(c, mode, d_aux, d_image);
+}
+
+int ebo_window_ref_time(int64_t t_first_us, int64_t t_last_us, int64_t* t_ref_us)
+{
+	if (!t_ref_us)
+	{
+		return EBO_ERR_ARG;
+	}
+	return mid_timestamp(t_first_us, t_last_us, *t_ref_us) ? EBO_OK : EBO_ERR_RANGE;
+}
+
+int ebo_count_image_shard_device(ebo_ctx* c, int n_windows, const int64_t* window_t_ref_us, const double* d_flows_grid,
+								 double* d_image)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (n_windows <= 0 || !window_t_ref_us || !d_flows_grid || !d_image)
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image_shard");
+	}
+	if (!c->custom_n)
+	{
+		return c->fail(EBO_ERR_STATE, "ebo_count_image_shard needs the units of a shard (ebo_set_patches)");
+	}
+	if (c->custom_n % n_windows != 0)
+	{
+		return c->fail(EBO_ERR_ARG, "the loaded units are not n_windows equal groups");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const int per = c->custom_n / n_windows;
+	// dt of an event against the WINDOW's reference time = dt against the unit's + dtWin: both int32
+	std::vector<int32_t> dtw(static_cast<size_t>(c->custom_n), 0);
+	for (int k = 0; k < c->custom_n; ++k)
+	{
+		if (c->units[k].n_ev == 0)
+		{
+			continue;
+		}
+		const int64_t tw = window_t_ref_us[k / per];
+		const int64_t d = tw - c->unit_tref[k];
+		if (d < INT32_MIN || d > INT32_MAX || tw - c->unit_tmin[k] > INT32_MAX || tw - c->unit_tmax[k] < INT32_MIN)
+		{
+			return c->fail(EBO_ERR_RANGE, "window reference time further than 2^31 us from a unit's events");
+		}
+		dtw[k] = static_cast<int32_t>(d);
+	}
+	int rc = ensure_aux(c, dtw.size() * sizeof(int32_t));
+	if (rc)
+	{
+		return rc;
+	}
+	rc = c->hip(hipMemcpyAsync(c->d_aux, dtw.data(), dtw.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream),
+				"H2D shard time offsets");
+	if (rc == EBO_OK)
+	{
+		// dtw is a local: the copy must have left host memory before it goes out of scope
+		rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipMemsetAsync(d_image, 0, static_cast<size_t>(n_windows) * c->prm.image_w * c->prm.image_h * sizeof(double),
+								   c->stream),
+					"zero shard image");
+	}
+	if (rc)
+	{
+		return rc;
+	}
+	if (launch_count_shard(c->d_events, c->d_units, c->custom_n, per, static_cast<const int32_t*>(c->d_aux), d_flows_grid,
+						   d_image, make_consts(c), c->stream))
+	{
+		return c->fail(EBO_ERR_HIP, "k_count_shard launch failed");
+	}
+	return EBO_OK;
+}
+
+int ebo_count_image_shard(ebo_ctx* c, int n_windows, const int64_t* window_t_ref_us, const double* flows_grid, double* image)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (n_windows <= 0 || !window_t_ref_us || !flows_grid || !image)
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image_shard");
+	}
+	if (static_cast<size_t>(n_windows) > static_cast<size_t>(c->cap_windows))
+	{
+		return c->fail(EBO_ERR_ARG, "more windows than max_windows");
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t fbytes = static_cast<size_t>(n_windows) * c->P * 2 * sizeof(double);
+	const size_t ibytes = static_cast<size_t>(n_windows) * c->prm.image_w * c->prm.image_h * sizeof(double);
+	int rc = c->hip(hipMemcpyAsync(c->d_flows, flows_grid, fbytes, hipMemcpyHostToDevice, c->stream), "H2D flows");
+	if (rc == EBO_OK)
+	{
+		rc = ebo_count_image_shard_device(c, n_windows, window_t_ref_us, c->d_flows, c->d_image);
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipMemcpyAsync(image, c->d_image, ibytes, hipMemcpyDeviceToHost, c->stream), "D2H image");
+	}
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	}
+	return rc;
 }
 
 int ebo_compensate_events_contrast(ebo_ctx* c, const ebo_event* ev, size_t n,

@@ -28,6 +28,8 @@ struct RcclApi
 	int (*GetUniqueId)(void*) = nullptr;
 	int (*CommInitRank)(void**, int, ebo_comm_id, int) = nullptr;
 	int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+	int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
 	int (*CommDestroy)(void*) = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
 };
@@ -57,9 +59,11 @@ RcclApi* rccl_api(std::string& err)
 	api.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
 	api.CommInitRank = reinterpret_cast<int (*)(void**, int, ebo_comm_id, int)>(dlsym(h, "ncclCommInitRank"));
 	api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
+	api.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+	api.Reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t)>(dlsym(h, "ncclReduce"));
 	api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
 	api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
-	if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy)
+	if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.AllReduce || !api.Reduce || !api.CommDestroy)
 	{
 		err = "librccl.so lacks the expected nccl* symbols";
 		dlclose(h);
@@ -140,9 +144,125 @@ int ebo_allgather_device(ebo_ctx* c, const double* d_send, double* d_recv, size_
 	return EBO_OK;
 }
 
+int ebo_comm_size(const ebo_ctx* c, int* rank, int* nranks)
+{
+	if (!c || (!rank && !nranks))
+	{
+		return EBO_ERR_ARG;
+	}
+	if (rank)
+	{
+		*rank = c->comm ? c->comm_rank : 0;
+	}
+	if (nranks)
+	{
+		*nranks = c->comm ? c->comm_size : 1;
+	}
+	return EBO_OK;
+}
+
+int ebo_reduce_sum_device(ebo_ctx* c, const double* d_send, double* d_recv, size_t count, int root)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!c->comm)
+	{
+		return c->fail(EBO_ERR_STATE, "no communicator: call ebo_comm_init first");
+	}
+	if (!d_send || (!d_recv && (root < 0 || root == c->comm_rank)) || root >= c->comm_size)
+	{
+		return c->fail(EBO_ERR_ARG, "bad argument to ebo_reduce_sum_device");
+	}
+	std::string err;
+	RcclApi* api = rccl_api(err);
+	const int rc = root < 0 ? api->AllReduce(d_send, d_recv, count, 8 /* ncclFloat64 */, 0 /* ncclSum */, c->comm, c->stream)
+							: api->Reduce(d_send, d_recv, count, 8, 0, root, c->comm, c->stream);
+	if (rc != 0)
+	{
+		return c->fail(EBO_ERR_COMM, std::string(root < 0 ? "ncclAllReduce: " : "ncclReduce: ") +
+										 (api->GetErrorString ? api->GetErrorString(rc) : "error"));
+	}
+	return EBO_OK;
+}
+
 // Config 5's exchange: variable-length per-rank lists of 32-byte track records.
 // Layout of the context's scratch: [send: maxN records][recv: nranks x maxN records]; the
 // counts travel first through the head of the same buffer.
+//
+// Collective discipline: a rank must never leave between two collectives on a condition the other
+// ranks do not share, or they wait in the next collective for ever.  So everything a rank decides
+// BEFORE the second all-gather is decided from the gathered counts (the same on every rank); the
+// conditions that are this rank's own (output buffer too small, its count echoed back changed) are
+// reported AFTER the rank has taken part in the second all-gather.
+namespace
+{
+// the counts collective alone: cnt[nranks] on every rank
+int gather_track_counts(ebo_ctx* c, RcclApi* api, size_t n_local, std::vector<uint64_t>& cnt)
+{
+	const size_t nr = static_cast<size_t>(c->comm_size);
+	int rc = ensure_scratch(c, (nr + 1) * sizeof(uint64_t));
+	if (rc)
+	{
+		return rc;
+	}
+	uint64_t* d_cnt = static_cast<uint64_t*>(c->d_scratch);
+	const uint64_t mine = n_local;
+	cnt.assign(nr, 0);
+	hipError_t e = hipMemcpyAsync(d_cnt, &mine, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `mine` is a local
+	if (e != hipSuccess)
+	{
+		return c->hip(e, "H2D track count");
+	}
+	const int nrc = api->AllGather(d_cnt, d_cnt + 1, 1, 5 /* ncclUint64 */, c->comm, c->stream);
+	if (nrc != 0)
+	{
+		return c->fail(EBO_ERR_COMM, std::string("ncclAllGather(counts): ") + (api->GetErrorString ? api->GetErrorString(nrc) : "error"));
+	}
+	e = hipMemcpyAsync(cnt.data(), d_cnt + 1, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	return c->hip(e, "track counts");
+}
+}  // namespace
+
+int ebo_allgather_track_counts(ebo_ctx* c, size_t n_local, size_t* n_all, size_t* counts)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!c->comm)
+	{
+		return c->fail(EBO_ERR_STATE, "no communicator: call ebo_comm_init first");
+	}
+	if (!n_all)
+	{
+		return c->fail(EBO_ERR_ARG, "null pointer");
+	}
+	std::string err;
+	RcclApi* api = rccl_api(err);
+	(void)hipSetDevice(c->prm.device);
+	std::vector<uint64_t> cnt;
+	const int rc = gather_track_counts(c, api, n_local, cnt);
+	if (rc)
+	{
+		return rc;
+	}
+	size_t total = 0;
+	for (size_t q = 0; q < cnt.size(); ++q)
+	{
+		total += cnt[q];
+		if (counts)
+		{
+			counts[q] = cnt[q];
+		}
+	}
+	*n_all = total;
+	return EBO_OK;
+}
+
 int ebo_allgather_tracks(ebo_ctx* c, const ebo_track_point* local, size_t n_local, ebo_track_point* all,
 						 size_t cap, size_t* n_all, size_t* counts)
 {
@@ -163,30 +283,12 @@ int ebo_allgather_tracks(ebo_ctx* c, const ebo_track_point* local, size_t n_loca
 	RcclApi* api = rccl_api(err);
 	(void)hipSetDevice(c->prm.device);
 	const size_t nr = static_cast<size_t>(c->comm_size);
-	int rc = ensure_scratch(c, (nr + 1) * sizeof(uint64_t));
+	// 1. counts
+	std::vector<uint64_t> cnt;
+	int rc = gather_track_counts(c, api, n_local, cnt);
 	if (rc)
 	{
 		return rc;
-	}
-	// 1. counts
-	uint64_t* d_cnt = static_cast<uint64_t*>(c->d_scratch);
-	const uint64_t mine = n_local;
-	std::vector<uint64_t> cnt(nr, 0);
-	hipError_t e = hipMemcpyAsync(d_cnt, &mine, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "H2D track count");
-	}
-	int nrc = api->AllGather(d_cnt, d_cnt + 1, 1, 5 /* ncclUint64 */, c->comm, c->stream);
-	if (nrc != 0)
-	{
-		return c->fail(EBO_ERR_COMM, std::string("ncclAllGather(counts): ") + (api->GetErrorString ? api->GetErrorString(nrc) : "error"));
-	}
-	e = hipMemcpyAsync(cnt.data(), d_cnt + 1, nr * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	if (e != hipSuccess)
-	{
-		return c->hip(e, "track counts");
 	}
 	size_t total = 0, maxN = 0;
 	for (size_t q = 0; q < nr; ++q)
@@ -199,40 +301,42 @@ int ebo_allgather_tracks(ebo_ctx* c, const ebo_track_point* local, size_t n_loca
 		}
 	}
 	*n_all = total;
-	if (cnt[static_cast<size_t>(c->comm_rank)] != n_local)
-	{
-		return c->fail(EBO_ERR_COMM, "track count of this rank came back changed");
-	}
-	if (total > cap)
-	{
-		return c->fail(EBO_ERR_ARG, "track output buffer too small");
-	}
-	if (maxN == 0)
+	if (maxN == 0)  // the same on every rank
 	{
 		return EBO_OK;
 	}
-	// 2. one all-gather of max-padded records
+	// 2. one all-gather of max-padded records -- every rank takes part, whatever its own buffer holds
+	const bool fits = total <= cap;
+	const bool echoed = cnt[static_cast<size_t>(c->comm_rank)] == n_local;
 	const size_t slot = maxN * sizeof(ebo_track_point);
 	rc = ensure_scratch(c, (nr + 1) * slot);
 	if (rc)
 	{
-		return rc;
+		return rc;  // out of device memory: nothing a rank can do for the others here
 	}
 	char* d_send = static_cast<char*>(c->d_scratch);
 	char* d_recv = d_send + slot;
-	e = hipMemsetAsync(d_send, 0, slot, c->stream);
+	hipError_t e = hipMemsetAsync(d_send, 0, slot, c->stream);
 	if (e == hipSuccess && n_local)
 	{
-		e = hipMemcpyAsync(d_send, local, n_local * sizeof(ebo_track_point), hipMemcpyHostToDevice, c->stream);
+		e = hipMemcpyAsync(d_send, local, std::min<size_t>(n_local, maxN) * sizeof(ebo_track_point), hipMemcpyHostToDevice,
+						   c->stream);
 	}
+	const int nrc = api->AllGather(d_send, d_recv, slot, 0 /* ncclInt8 */, c->comm, c->stream);
 	if (e != hipSuccess)
 	{
+		(void)hipStreamSynchronize(c->stream);
 		return c->hip(e, "H2D tracks");
 	}
-	nrc = api->AllGather(d_send, d_recv, slot, 0 /* ncclInt8 */, c->comm, c->stream);
 	if (nrc != 0)
 	{
 		return c->fail(EBO_ERR_COMM, std::string("ncclAllGather(tracks): ") + (api->GetErrorString ? api->GetErrorString(nrc) : "error"));
+	}
+	if (!echoed || !fits)
+	{
+		(void)hipStreamSynchronize(c->stream);
+		return !echoed ? c->fail(EBO_ERR_COMM, "track count of this rank came back changed")
+					   : c->fail(EBO_ERR_ARG, "track output buffer too small");
 	}
 	// compacting copies: rank q's real records only
 	size_t at = 0;

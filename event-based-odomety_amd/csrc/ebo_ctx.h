@@ -110,6 +110,7 @@ struct ebo_ctx
 
 	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window
 	std::vector<int64_t> unit_tref;
+	std::vector<int64_t> unit_tmin, unit_tmax;  // ebo_set_patches: earliest / latest event time per unit (ebo_count_image_shard)
 	std::vector<WindowInfo> windows;
 	std::vector<uint64_t> h_packed;
 	// pinned, device-visible staging of one evaluation round (flows in, (r, J0, J1) out, modes):

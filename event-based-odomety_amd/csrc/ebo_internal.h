@@ -140,6 +140,8 @@ struct EdgeLaunch
 	EvalConsts c;
 	EdgeConsts ec;
 };
+int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,
+					   const int32_t* d_dtwin, const double* d_flows, double* d_image, const EvalConsts& c, void* stream);
 int launch_eval_edge(const EdgeLaunch& L, void* stream);
 int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows_out, int32_t* d_stats, void* stream);
 

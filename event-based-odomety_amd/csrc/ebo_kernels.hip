@@ -950,6 +950,13 @@ struct LmUnit
 	int numInvalid;
 	double c0, c1, modelCostChange, candCost, quality;
 
+	// Where the objective needs the registers (the edge loss), the state lives in LDS and ONE lane
+	// runs the solver between two evaluations (k_solve_edge): replicated in every lane it is ~100
+	// VGPRs that stay live across the objective (176-185 spilled VGPRs, ~0.5 KB of scratch per lane in
+	// round 2), and replicated in every WAVE the solver's serial f64 code (divisions, square roots)
+	// cost the workgroup as many vector instructions as a value-only evaluation itself.
+	int more;  // k_solve_edge: advance()'s answer, for the other waves
+
 	__device__ __forceinline__ void begin()
 	{
 		best0 = best1 = 0.0;
@@ -2058,6 +2065,36 @@ __global__ void k_count_stray(const uint64_t* __restrict__ events, const Unit* _
 		stray_flow(rec, windowFlows, c, m0, m1);
 		int nx, ny;
 		if (count_target<1>(rec, true, un.dt_win, m0, m1, nullptr, c, nx, ny))
+		{
+			unsafeAtomicAdd(&img[static_cast<size_t>(ny) * c.image_w + nx], 1.0);  // exact on integer counts
+		}
+	}
+}
+
+// The final image of warped events (feature_detector.cpp:433-463) of windows whose patches are SHARDED
+// over ranks (BASELINE config 4): the context holds, per window, the units of this rank's
+// patch rows (ebo_set_patches), `flows` are those of ALL patches of the grid (after the all-gather of
+// the solved flows) and dtWin[unit] = t_ref(window) - t_ref(unit) with the WINDOW's reference time,
+// which a shard cannot derive from its own events.  Workgroup = unit; every event takes the flow of
+// the grid patch its own coordinates select (:436-441) and adds 1.0 at its rounded warped position.
+// The partial images of the ranks are integer-valued doubles: their sum is exact in any order.
+__global__ void k_count_shard(const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
+							  const int32_t* __restrict__ dtWin, const double* __restrict__ flows,
+							  double* __restrict__ image, EvalConsts c)
+{
+	const Unit un = units[blockIdx.x];
+	const int w = blockIdx.x / unitsPerWindow;
+	const int P = c.npx * c.npy;
+	const double* windowFlows = flows + 2 * static_cast<size_t>(w) * P;
+	double* img = image + static_cast<size_t>(w) * c.image_w * c.image_h;
+	const int dtw = dtWin[blockIdx.x];
+	for (uint32_t e = threadIdx.x; e < un.n_ev; e += blockDim.x)
+	{
+		const uint64_t rec = events[un.ev_off + e];
+		double m0, m1;
+		stray_flow(rec, windowFlows, c, m0, m1);
+		int nx, ny;
+		if (count_target<1>(rec, true, dtw, m0, m1, nullptr, c, nx, ny))
 		{
 			unsafeAtomicAdd(&img[static_cast<size_t>(ny) * c.image_w + nx], 1.0);  // exact on integer counts
 		}
@@ -3231,6 +3268,19 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 	Rec24 r;
 	r.p = static_cast<const RawEvent*>(L.d_raw);
 	return launch_bucket_t(L, r, s);
+}
+
+int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,
+					   const int32_t* d_dtwin, const double* d_flows, double* d_image, const EvalConsts& c, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (n_units == 0)
+	{
+		return 0;
+	}
+	hipLaunchKernelGGL(k_count_shard, dim3(n_units), dim3(256), 0, s, d_events, d_units, units_per_window, d_dtwin,
+					   d_flows, d_image, c);
+	return check_launch();
 }
 
 int launch_eval_edge(const EdgeLaunch& L, void* stream)

@@ -629,7 +629,7 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 		return c->fail(EBO_ERR_ARG, "more events than max_events");
 	}
 	std::vector<Unit> units(n_patches);
-	std::vector<int64_t> utref(n_patches, 0);
+	std::vector<int64_t> utref(n_patches, 0), utmin(n_patches, 0), utmax(n_patches, 0);
 	c->h_packed.resize(total);
 	int mrw = 0, mrh = 0;
 	size_t base = 0;
@@ -665,8 +665,11 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 			return c->fail(EBO_ERR_RANGE, "patch mid-time outside int32 microseconds");
 		}
 		utref[p] = tu;
+		int64_t tlo = n ? pe[0].t_us : 0, thi = tlo;
 		for (size_t i = 0; i < n; ++i)
 		{
+			tlo = std::min<int64_t>(tlo, pe[i].t_us);
+			thi = std::max<int64_t>(thi, pe[i].t_us);
 			if (pe[i].x < kCoordMin || pe[i].x > kCoordMax || pe[i].y < kCoordMin || pe[i].y > kCoordMax)
 			{
 				return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
@@ -688,6 +691,8 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 			std::sort(c->h_packed.begin() + static_cast<std::ptrdiff_t>(base),
 					  c->h_packed.begin() + static_cast<std::ptrdiff_t>(base + n));
 		}
+		utmin[p] = tlo;
+		utmax[p] = thi;
 		base += n;
 	}
 	(void)hipSetDevice(c->prm.device);
@@ -716,6 +721,8 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 	}
 	c->units.swap(units);
 	c->unit_tref.swap(utref);
+	c->unit_tmin.swap(utmin);
+	c->unit_tmax.swap(utmax);
 	c->windows.assign(1, WindowInfo{0, total});
 	c->n_windows = 1;
 	c->custom_n = n_patches;

@@ -47,27 +47,27 @@ inline void saveFeaturesTrajectory(const tracker::Patches& patches, const std::s
 }
 
 // all ranks' tracks on every rank; `counts` (optional) receives the per-rank record counts.
-// ctx must carry a communicator (ebo_comm_init).
+// ctx must carry a communicator (ebo_comm_init); every rank of it must make this call.
 inline std::vector<ebo_track_point> gatherFeaturesTrajectories(ebo_ctx* ctx, const tracker::Patches& patches,
-															   std::vector<size_t>* counts = nullptr, int nranks = 1)
+															   std::vector<size_t>* counts = nullptr)
 {
 	const std::vector<ebo_track_point> mine = trackPoints(patches);
-	std::vector<size_t> cnt(static_cast<size_t>(nranks > 0 ? nranks : 1), 0);
+	int nranks = 1;
+	if (ebo_comm_size(ctx, nullptr, &nranks) != EBO_OK || nranks < 1)
+	{
+		throw std::runtime_error("tools::gatherFeaturesTrajectories: no context");
+	}
+	std::vector<size_t> cnt(static_cast<size_t>(nranks), 0);  // sized from the communicator, never from the caller
 	size_t total = 0;
-	// first call sizes the result (cap 0 reports the total), second call fills it
-	int rc = ebo_allgather_tracks(ctx, mine.data(), mine.size(), nullptr, 0, &total, cnt.data());
-	if (rc != EBO_OK && !(rc == EBO_ERR_ARG && total > 0))
+	// the counts collective sizes the result, the gather fills it (both on every rank)
+	if (ebo_allgather_track_counts(ctx, mine.size(), &total, cnt.data()) != EBO_OK)
 	{
 		throw std::runtime_error(std::string("tools::gatherFeaturesTrajectories: ") + ebo_last_error(ctx));
 	}
 	std::vector<ebo_track_point> all(total);
-	if (total)
+	if (ebo_allgather_tracks(ctx, mine.data(), mine.size(), all.data(), all.size(), &total, cnt.data()) != EBO_OK)
 	{
-		rc = ebo_allgather_tracks(ctx, mine.data(), mine.size(), all.data(), all.size(), &total, cnt.data());
-		if (rc != EBO_OK)
-		{
-			throw std::runtime_error(std::string("tools::gatherFeaturesTrajectories: ") + ebo_last_error(ctx));
-		}
+		throw std::runtime_error(std::string("tools::gatherFeaturesTrajectories: ") + ebo_last_error(ctx));
 	}
 	if (counts)
 	{

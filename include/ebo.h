@@ -326,6 +326,23 @@ int ebo_route_events(ebo_ctx* ctx, int n_patches, const double* rects, const uin
 					 const uint32_t* max_take, uint32_t cap, uint32_t* out_index, uint32_t* out_count,
 					 uint32_t* out_next);
 
+/* R2's final loop (:433-463) for windows whose PATCHES ARE SHARDED over ranks (BASELINE
+ * config 4).  The context was loaded by ebo_set_patches with n_windows equal groups of units (group w =
+ * this rank's patches of window w with the events inside them); flows_grid [n_windows][P][2] are the flows
+ * of ALL P patches of the context's grid (every rank has them after the all-gather of the solved flows);
+ * window_t_ref_us [n_windows] (host) is each WINDOW's reference time (:305-306), which a shard cannot
+ * derive from its own events: ebo_window_ref_time(first, last) of the whole window's first / last event
+ * time.  image [n_windows][image_h][image_w] receives the counts of THIS context's events only, each
+ * warped by the flow of the grid patch its own coordinates select (:436-441); the sum of the ranks'
+ * images (ebo_reduce_sum_device, or any reduce: integer-valued doubles add exactly) is the image
+ * ebo_compensate_events_contrast returns for the whole window.  _device: pointers on the device,
+ * asynchronous.  EBO_ERR_STATE without ebo_set_patches. */
+int ebo_window_ref_time(int64_t t_first_us, int64_t t_last_us, int64_t* t_ref_us);
+int ebo_count_image_shard(ebo_ctx* ctx, int n_windows, const int64_t* window_t_ref_us, const double* flows_grid,
+						  double* image);
+int ebo_count_image_shard_device(ebo_ctx* ctx, int n_windows, const int64_t* window_t_ref_us,
+								 const double* d_flows_grid, double* d_image);
+
 /* R2 in one call: set window, solve, final warped count image.
  * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */
 int ebo_compensate_events_contrast(ebo_ctx* ctx, const ebo_event* ev, size_t n,
@@ -367,6 +384,13 @@ typedef struct ebo_comm_id
 int ebo_comm_unique_id(ebo_comm_id* id);
 int ebo_comm_init(ebo_ctx* ctx, const ebo_comm_id* id, int rank, int nranks);
 int ebo_allgather_device(ebo_ctx* ctx, const double* d_send, double* d_recv, size_t count_per_rank);
+/* Rank and size of the context's communicator (0 and 1 without one). */
+int ebo_comm_size(const ebo_ctx* ctx, int* rank, int* nranks);
+/* Element-wise sum over the ranks of count doubles, asynchronously on the context's stream: into d_recv on
+ * `root` (ncclReduce; d_recv may be NULL elsewhere) or, root < 0, on every rank (ncclAllReduce).  The one
+ * reduce of SURVEY 8(e)'s "final full-frame count image": the per-rank partial images of
+ * ebo_count_image_shard are integer-valued doubles, so the sum is exact in whatever order RCCL adds. */
+int ebo_reduce_sum_device(ebo_ctx* ctx, const double* d_send, double* d_recv, size_t count, int root);
 int ebo_comm_destroy(ebo_ctx* ctx);
 
 /* One sample of a tracked feature's trajectory, the record tools::Evaluator::saveFeaturesTrajectory
@@ -384,11 +408,15 @@ typedef struct ebo_track_point
  * every rank receives all of them, rank 0's first, each rank's in the order given.  Two
  * collectives on the context's stream: an all-gather of the counts, then ONE ncclAllGather of
  * max-count-padded 32-byte records; the padding is dropped on the way back to the host.
- * all [cap] (host) receives *n_all records; counts [nranks] (may be NULL) the per-rank counts.
- * EBO_ERR_STATE without ebo_comm_init; EBO_ERR_ARG when cap is too small (*n_all and counts are
- * still set, nothing is written to all).  Synchronous. */
+ * all [cap] (host) receives *n_all records; counts [nranks = ebo_comm_size] (may be NULL) the per-rank
+ * counts.  EBO_ERR_STATE without ebo_comm_init; EBO_ERR_ARG when cap is too small (*n_all and counts are
+ * still set, nothing is written to all).  Synchronous.  Every rank of the communicator must call it, and a
+ * rank whose cap is too small still takes part in BOTH collectives before it returns the error, so the
+ * others never wait for it; size the buffer with ebo_allgather_track_counts (the counts collective alone,
+ * also on every rank) rather than with a cap = 0 call. */
 int ebo_allgather_tracks(ebo_ctx* ctx, const ebo_track_point* local, size_t n_local, ebo_track_point* all,
 						 size_t cap, size_t* n_all, size_t* counts);
+int ebo_allgather_track_counts(ebo_ctx* ctx, size_t n_local, size_t* n_all, size_t* counts);
 
 /* trajectory.txt as saveFeaturesTrajectory writes it (evaluator.cpp:125-150): one line
  * "<id> <seconds> <x> <y>" per point, std::fixed with 8 decimals, seconds =

@@ -4,7 +4,10 @@ over gloo on host copies; layout, sharding and every kernel are the ones an 8-GP
 
 Rank r loads the patches of its grid rows of every window with the events inside them
 (ebo_shard_range + ebo_set_patches), solves them on the device (ebo_solve_device), and ONE
-all-gather gives every rank all flows.  Every rank saves what it received."""
+all-gather gives every rank all flows.  Every rank saves what it received.  Then the last third of
+compensateEventsContrast (feature_detector.cpp:433-463): every rank counts ITS events warped by the
+gathered flows at the window's reference time (ebo_count_image_shard) and ONE reduce sums the
+integer-valued partial images; rank 0 saves the result."""
 import importlib
 import os
 import sys
@@ -35,9 +38,11 @@ def main():
     b, e = ebo.shard_range(npy, rank, world)
     _, _, rects = synth.grid_rects(cfg["image"], cfg["patch"])
     my_rects = rects[b * npx:e * npx]
-    evs, cnts = [], []
+    evs, cnts, t_ref = [], [], []
     for w in range(n_windows):
         ev, _ = synth.make_window(config, window=w, n_events=min(cfg["events"], 40000))
+        # the WINDOW's reference time: from its first / last event, known to whoever cut the window
+        t_ref.append(ebo.window_ref_time(ev["t_us"][0], ev["t_us"][-1]))
         ev_w, c_w = bench.bucket_rows(ev, cfg, b, e)
         evs.append(ev_w)
         cnts.append(c_w)
@@ -54,14 +59,23 @@ def main():
         torch.cuda.synchronize()
         counts = [n_windows * q * npx for q in rows]
         full = exchange.allgather_rows(d_sol.cpu(), counts)
-    # rank q's block is [window][its rows][px]; reorder to [window][row][px] = patch order
-    parts = []
-    at = 0
-    for q in range(world):
-        parts.append(full[at:at + counts[q]].reshape(n_windows, rows[q] * npx, 2))
-        at += counts[q]
-    flows = torch.cat(parts, dim=1).numpy()
-    np.save(os.path.join(out_dir, "flows_rank%d.npy" % rank), flows)
+        # rank q's block is [window][its rows][px]; reorder to [window][row][px] = patch order
+        parts = []
+        at = 0
+        for q in range(world):
+            parts.append(full[at:at + counts[q]].reshape(n_windows, rows[q] * npx, 2))
+            at += counts[q]
+        flows = torch.cat(parts, dim=1).contiguous()
+        np.save(os.path.join(out_dir, "flows_rank%d.npy" % rank), flows.numpy())
+        # the final image: partial image of this rank's events on the device, one reduce
+        d_flows = flows.to("cuda")
+        d_img = torch.zeros((n_windows, ih, iw), dtype=torch.float64, device="cuda")
+        c.count_image_shard_device(n_windows, t_ref, d_flows.data_ptr(), d_img.data_ptr())
+        torch.cuda.synchronize()
+        img = d_img.cpu()
+        dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "image_rank0.npy"), img.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

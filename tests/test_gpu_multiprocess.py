@@ -23,7 +23,7 @@ def _torchrun(world, port, script, *argv, env=None, timeout=900):
 
 
 @pytest.mark.parametrize("config,world,n_windows", [(2, 2, 3), (0, 3, 2)])
-def test_sharded_device_solve_and_gather_equals_one_process(tmp_path, ebo, synth, config, world, n_windows):
+def test_sharded_device_solve_gather_and_final_image_equal_one_process(tmp_path, ebo, synth, config, world, n_windows):
     iters = 8
     res = _torchrun(world, 29540 + world, os.path.join(HERE, "mp_gpu_worker.py"), tmp_path, config, n_windows, iters)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -40,7 +40,12 @@ def test_sharded_device_solve_and_gather_equals_one_process(tmp_path, ebo, synth
         c.set_windows(ev, offs)
         whole, _ = c.solve(mode=ebo.SOLVE_INDEPENDENT, max_num_iterations=iters)
         act = np.array([[c.patch_info(p, w)[1] for p in range(c.P)] for w in range(n_windows)])
-    first = np.load(os.path.join(str(tmp_path), "flows_rank0.npy"))
+        first = np.load(os.path.join(str(tmp_path), "flows_rank0.npy"))
+        # config 4 END TO END: the reduced partial images of the ranks = the one-process final image
+        # (feature_detector.cpp:433-463) at the same flows, bit for bit
+        image = np.load(os.path.join(str(tmp_path), "image_rank0.npy"))
+        assert np.array_equal(image, c.count_image(ebo.COUNT_WARPED, first))
+        assert image.sum() > 0.9 * len(ev)
     for r in range(1, world):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "flows_rank%d.npy" % r)), first)  # every rank: all flows
     assert first.shape == whole.shape

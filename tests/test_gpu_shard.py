@@ -49,3 +49,78 @@ def test_patch_row_shards_equal_the_whole_window(ebo, synth, config, world):
     assert np.array_equal(rr[act], r[0][act])
     np.testing.assert_allclose(JJ[act], J[0][act], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(ss[act], solved[0][act], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("config,world,n_windows,stray", [(0, 2, 2, 0), (2, 3, 1, 40), (3, 8, 2, 25), (4, 8, 1, 0)])
+def test_partial_count_images_of_the_shards_sum_to_the_whole_image(ebo, synth, config, world, n_windows, stray):
+    """Config 4 end to end (SURVEY 8(e) "final full-frame count image", feature_detector.cpp:433-463): every
+    rank counts ITS events (ebo_set_patches + ebo_count_image_shard) warped by the gathered flows of ALL
+    patches at the WINDOW's reference time; the partial images are integer-valued, their sum equals the
+    one-process image bit for bit -- with events outside the sensor (they take the clamped patch's flow
+    and live on that patch's rank), large flows that carry events across shard borders, several windows."""
+    cfg = synth.CONFIGS[config]
+    iw, ih = cfg["image"]
+    pw, ph = cfg["patch"]
+    rng = np.random.default_rng(11 + config)
+    evs, offs = [], [0]
+    for w in range(n_windows):
+        ev, _ = synth.make_window(config, window=w, n_events=min(cfg["events"], 120000))
+        if stray:
+            k = rng.choice(len(ev), stray, replace=False)
+            ev = ev.copy()
+            ev["x"][k[: stray // 2]] = rng.integers(-30, 0, stray // 2)
+            ev["y"][k[stray // 2:]] = ih + rng.integers(0, 30, stray - stray // 2)
+        evs.append(ev)
+        offs.append(offs[-1] + len(ev))
+    allev = np.concatenate(evs)
+    kw = dict(image_w=iw, image_h=ih, patch_w=pw, patch_h=ph, loss=ebo.LOSS_VARIANCE, tv_weight=0.0,
+              max_events=len(allev), max_windows=n_windows)
+    with ebo.Context(**kw) as c:
+        c.set_windows(allev, offs)
+        npx, npy, P = c.npx, c.npy, c.P
+        flows = rng.uniform(-6.0, 6.0, (n_windows, P, 2))  # up to +-150 px over a 50 ms window: far across shard borders
+        whole = c.count_image(ebo.COUNT_WARPED, flows)
+        rects = np.array([c.patch_rect(p % npx, p // npx) for p in range(P)])
+        t_ref = [c.window_info(w)[0] for w in range(n_windows)]
+    for w in range(n_windows):
+        assert t_ref[w] == ebo.window_ref_time(evs[w]["t_us"][0], evs[w]["t_us"][-1])
+    total = np.zeros_like(whole)
+    for rank in range(world):
+        b, e = ebo.shard_range(npy, rank, world)
+        if b == e:
+            continue
+        my = np.arange(b * npx, e * npx)
+        sev, soffs = [], [0]
+        for w in range(n_windows):
+            ev = evs[w]
+            # the patch of the final loop (:436-441): index clamped into the grid, also for stray events
+            gx = np.clip(np.trunc(ev["x"] / pw).astype(np.int64), 0, npx - 1)
+            gy = np.clip(np.trunc(ev["y"] / ph).astype(np.int64), 0, npy - 1)
+            pid = gy * npx + gx
+            for p in my:
+                sel = ev[pid == p]
+                sev.append(sel)
+                soffs.append(soffs[-1] + len(sel))
+        with ebo.Context(**kw) as c:
+            c.set_patches(np.concatenate(sev), soffs, np.tile(rects[my], (n_windows, 1)))
+            part = c.count_image_shard(n_windows, t_ref, flows)
+        assert np.array_equal(part, np.round(part)) and part.min() >= 0
+        total += part
+    assert np.array_equal(total, whole)
+    assert whole.sum() > 0.5 * len(allev)
+
+
+def test_count_image_shard_argument_errors(ebo, synth):
+    ev, _ = synth.make_window(0, n_events=3000)
+    with ebo.Context(max_events=len(ev), max_windows=2) as c:
+        c.set_window(ev)
+        with pytest.raises(ebo.EboError) as err:  # a window context is not a shard
+            c.count_image_shard(1, [0], np.zeros((1, c.P, 2)))
+        assert err.value.code == ebo.ERR_STATE
+        c.set_patches(ev, [0, 1000, 3000], [(0, 0, 20, 20), (20, 0, 20, 20)])
+        with pytest.raises(ebo.EboError) as err:  # 2 units are not 3 equal groups
+            c.count_image_shard(3, [0, 0, 0], np.zeros((3, c.P, 2)))
+        assert err.value.code == ebo.ERR_ARG
+        with pytest.raises(ebo.EboError) as err:  # reference time 2^31 us away from the events
+            c.count_image_shard(1, [int(ev["t_us"][0]) + (1 << 32)], np.zeros((1, c.P, 2)))
+        assert err.value.code == ebo.ERR_RANGE
