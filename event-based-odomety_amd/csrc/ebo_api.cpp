@@ -225,9 +225,13 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	// one workgroup per CU (LDS-limited): a big workgroup is the only source of waves
 	// (measured, C2 x 64 windows: 256 threads 2.1, 512: 2.8, 1024: 3.3 Gevents/s)
 	L.block = static_cast<int>(env_size("EBO_EDGE_BLOCK", 0));
-	if (L.block != 0 && (L.block < 64 || L.block > 1024 || (L.block & 63)))
+	if (L.block != 0 && (L.block < 64 || L.block > 768 || (L.block & 63)))
 	{
-		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,1024]");
+		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,768]");
+	}
+	if (L.for_solve && L.block > 512)
+	{
+		L.block = 512;  // k_solve_edge is built for 256 and 512 lanes
 	}
 	const size_t headerBytes = (168 + 1024) * sizeof(double);  // kEdgeHeader
 	const size_t canvasPx = static_cast<size_t>(9) * c->max_rw * c->max_rh;
@@ -266,7 +270,10 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	L.cap_px = static_cast<int>((ldsBytes - headerBytes) / ldsPerPx);
 	if (L.block == 0)
 	{
-		L.block = (L.alias_lds && headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx <= 80 * 1024 - 256) ? 512 : 1024;
+		// two workgroups per CU: 256 lanes each (256 VGPRs); one per CU: 768 lanes (168 VGPRs) for the
+		// batched evaluation, 512 (256 VGPRs) for the device-resident solve -- ebo_edge.inc, MAXT
+		const bool twoPerCu = L.alias_lds && headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx <= 80 * 1024 - 256;
+		L.block = twoPerCu ? 256 : (L.for_solve ? 512 : 768);
 	}
 	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx;
 	L.scratch_stride = (canvasPx * (bytesPerPx + 1) + 256 + 255) & ~static_cast<size_t>(255);  // I, E, A, cnt + the argmax list (canvasPx / 4 + 64 ints)
@@ -866,6 +873,7 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 		E.flow_sets = 1;
 		E.fd_step = 0.0;
 		E.d_out = nullptr;
+		E.for_solve = true;
 		int rce = edge_launch_setup(c, E);
 		if (rce)
 		{

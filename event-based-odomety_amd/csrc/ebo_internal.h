@@ -137,6 +137,7 @@ struct EdgeLaunch
 	double* d_sets;       // staging [5][n_units][3] for central differences
 	double* d_out;        // [n_flow][3]
 	const unsigned char* d_modes = nullptr;  // per flow slot: 0 skip, 1 value, 2 value + Jacobian
+	bool for_solve = false;  // the launch is k_solve_edge (picks the workgroup size of its instantiations)
 	EvalConsts c;
 	EdgeConsts ec;
 };

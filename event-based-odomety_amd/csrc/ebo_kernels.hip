@@ -963,6 +963,7 @@ struct LmUnit
 		iteration = evalsCost = evalsJac = 0;
 		termination = 1;
 		phase = 0;
+		more = 1;
 		x0 = x1 = 0.0;  // feature_detector.cpp:318-326
 		q0 = q1 = 0.0;
 		qJac = true;
@@ -1206,19 +1207,41 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 
 	if (u.flags & kUnitActive)
 	{
-		LmUnit lm;
-		lm.begin();
-		double r, a, b;
-		do
+		// The solver state lives in LDS (the reduction scratch rows of waves 8..15, which a workgroup of
+		// at most 512 lanes never uses) and thread 0 runs the solver between two evaluations: replicated
+		// in every wave its serial f64 code (divisions, square roots) was a fifth of the workgroup's
+		// vector instructions, replicated in every lane ~100 VGPRs live across the objective.
+		static_assert(sizeof(LmUnit) <= 64 * sizeof(double), "LmUnit must fit red[64..127]");
+		LmUnit& lm = *reinterpret_cast<LmUnit*>(lds + 64);
+		if (threadIdx.x == 0)
 		{
-			eval_unit<FIXED>(ev, u, lm.q0, lm.q1, lm.qJac, capDoubles, c, lds, r, a, b);
-		} while (lm.advance(r, a, b, o));
-		iteration = lm.iteration;
-		evalsCost = lm.evalsCost;
-		evalsJac = lm.evalsJac;
-		termination = lm.termination;
-		best0 = lm.best0;
-		best1 = lm.best1;
+			lm.begin();
+		}
+		for (;;)
+		{
+			__syncthreads();  // the point to evaluate (or the end) is published; every thread is past the previous evaluation
+			if (!lm.more)
+			{
+				break;
+			}
+			const double q0 = lm.q0, q1 = lm.q1;
+			const bool qJac = lm.qJac;
+			double r, a, b;
+			eval_unit<FIXED>(ev, u, q0, q1, qJac, capDoubles, c, lds, r, a, b);
+			if (threadIdx.x == 0)
+			{
+				lm.more = lm.advance(r, a, b, o) ? 1 : 0;
+			}
+		}
+		if (threadIdx.x == 0)
+		{
+			iteration = lm.iteration;
+			evalsCost = lm.evalsCost;
+			evalsJac = lm.evalsJac;
+			termination = lm.termination;
+			best0 = lm.best0;
+			best1 = lm.best1;
+		}
 	}
 	if (threadIdx.x == 0 && !(u.flags & kUnitStray))
 	{
@@ -3290,8 +3313,14 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 	{
 		return 0;
 	}
-	auto edgeKern = L.alias_lds ? (L.want_jac ? k_eval_edge<true, true> : k_eval_edge<true, false>)
-								: (L.want_jac ? k_eval_edge<false, true> : k_eval_edge<false, false>);
+	using EdgeKern = decltype(&k_eval_edge<true, true, 256>);
+	const bool narrow = L.block <= 256;  // MAXT 256 (two workgroups per CU) or 768
+	auto pick = [&](auto alias, auto jac) -> EdgeKern {
+		constexpr bool A = decltype(alias)::value, J = decltype(jac)::value;
+		return narrow ? k_eval_edge<A, J, 256> : k_eval_edge<A, J, 768>;
+	};
+	EdgeKern edgeKern = L.alias_lds ? (L.want_jac ? pick(std::true_type(), std::true_type()) : pick(std::true_type(), std::false_type()))
+									: (L.want_jac ? pick(std::false_type(), std::true_type()) : pick(std::false_type(), std::false_type()));
 	if (allow_big_lds(edgeKern, L.lds_bytes))
 	{
 		return -2;
@@ -3318,7 +3347,14 @@ int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows
 	{
 		return 0;
 	}
-	auto kern = L.alias_lds ? k_solve_edge<true> : k_solve_edge<false>;
+	using SolveKern = decltype(&k_solve_edge<true, 256>);
+	if (L.block > 512)
+	{
+		return -2;  // the solve's instantiations are 256 and 512 lanes (edge_launch_setup clamps EBO_EDGE_BLOCK)
+	}
+	const bool narrow = L.block <= 256;
+	SolveKern kern = L.alias_lds ? (narrow ? k_solve_edge<true, 256> : k_solve_edge<true, 512>)
+								 : (narrow ? k_solve_edge<false, 256> : k_solve_edge<false, 512>);
 	if (allow_big_lds(kern, L.lds_bytes))
 	{
 		return -2;
