@@ -15,7 +15,11 @@ region.  Three workloads; `--workload auto` (default) picks by N:
             PATCH ROWS are sharded over the N GPUs (ebo_shard_range + ebo_set_patches: 32 grid
             rows -> 32/N rows = 1024/N patches per window per GPU).  A step = the device-resident
             per-patch solve of the rank's shard (ebo_solve_device, one launch) + ONE RCCL all-gather of
-            the solved flows (16 B per patch), after which every rank holds every window's flows.
+            the solved flows (16 B per patch), after which every rank holds every window's flows, + the
+            last third of compensateEventsContrast (feature_detector.cpp:433-463): every rank counts ITS
+            events warped by the gathered flows at the window's reference time (ebo_count_image_shard)
+            and ONE reduce sums the integer-valued partial images on rank 0 (`--no-c4-image` leaves
+            the step at solve + all-gather, as round 2 measured it).
             `--c4-windows` windows PER GPU are in flight (N x that many windows in the batch), so
             the per-GPU work is fixed as N grows: weak scaling.  value = event-evaluations of the
             solves (events x objective evaluations, from the solver's own statistics) per second.
@@ -49,6 +53,23 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X spec: f64 vector FMA, 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
+# Useful f64 operations of one edge-loss evaluation per item of work (DESIGN.md 4.5 derives them from
+# ebo_edge.inc; an FMA counts 2, an exp as its 22-operation polynomial, comparisons and address
+# arithmetic count nothing): scatter per event, conversion per box pixel, separable tensor filter +
+# eigenvalue per eigenvalue-region pixel (8-row runs: 14 / 8 row steps of 77 + 53), the eigenvector
+# direction per pixel of a Jacobian evaluation, reverse sweep per argmax entry, gather per event.
+EDGE_FLOPS = {"scatter_per_event": 290, "convert_per_box_pixel": 3, "eigen_per_pixel": 188, "direction_per_pixel": 14,
+              "reverse_per_entry": 860, "gather_per_event": 420}
+
+
+def edge_flops(stats, want_jac):
+    f = (stats["events"] * EDGE_FLOPS["scatter_per_event"] + stats["box_pixels"] * EDGE_FLOPS["convert_per_box_pixel"]
+         + stats["eigen_pixels"] * EDGE_FLOPS["eigen_per_pixel"])
+    if want_jac:
+        f += (stats["eigen_pixels"] * EDGE_FLOPS["direction_per_pixel"] + stats["argmax_entries"] * EDGE_FLOPS["reverse_per_entry"]
+              + stats["events"] * EDGE_FLOPS["gather_per_event"])
+    return float(f)
 BYTES_PER_EVENT_EVAL = 8  # packed {x:15, pol:1, y:15, dt:32}; SURVEY §8(d)
 
 
@@ -233,6 +254,19 @@ class Comm:
             return out
         return exchange.allgather_rows(t_local, counts, out=out)
 
+    def reduce_sum_to_rank0(self, t_dev):
+        """ONE reduce (sum) of a device tensor onto rank 0, in place there."""
+        if not self.active:
+            return t_dev
+        if self.backend == "gloo":
+            h = t_dev.cpu()
+            self.dist.reduce(h, dst=0, op=self.dist.ReduceOp.SUM)
+            if self.rank == 0:
+                t_dev.copy_(h)
+            return t_dev
+        self.dist.reduce(t_dev, dst=0, op=self.dist.ReduceOp.SUM)
+        return t_dev
+
     def allgather_tracks(self, exchange, local):
         if not self.active:
             return local, [len(local)]
@@ -269,6 +303,7 @@ def main():
     ap.add_argument("--windows", type=int, default=None, help="eval / replicas: independent windows per GPU per step")
     ap.add_argument("--c4-windows", type=int, default=4, help="c4: windows in flight PER GPU (batch = N x this)")
     ap.add_argument("--strong", action="store_true", help="c4: keep the batch at --c4-windows windows in total")
+    ap.add_argument("--no-c4-image", action="store_true", help="c4: stop the step at solve + all-gather (no final count image)")
     ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true")
@@ -294,6 +329,16 @@ def main():
     if args.windows is None:
         args.windows = 64 if args.config >= 3 else 256
     extras_on = rank == 0 and world == 1 and not args.no_extras and workload == "eval"
+
+    # N > 1: the CPU baseline of rank 0 runs BEFORE anything touches the GPU or the process group (the
+    # other ranks wait in the rendezvous), so that no rank sits in a collective while one computes
+    base_early = None
+    if world > 1 and rank == 0:
+        try:
+            synth_early = importlib.import_module("event-based-odomety_amd.synth")
+            base_early = cpu_baseline(synth_early, 3 if workload == "c4" else args.config, args.cpu_seconds)
+        except Exception as exc:
+            base_early = {"error": repr(exc)}
 
     cpu_all = None
     if extras_on:
@@ -372,12 +417,20 @@ def main():
         my_rects = rects[b * npx:e * npx]
         # a few distinct windows, repeated to fill the batch (a window's events are generated by
         # numpy at ~2 s per 1 M events; each copy has its own buffers and is solved on its own)
-        base = [bucket_rows(synth.make_window(4, window=w)[0], cfg, b, e) for w in range(min(distinct, windows_total))]
-        evs, cnts = [], []
+        base, base_tref = [], []
+        for w in range(min(distinct, windows_total)):
+            ev_full = synth.make_window(4, window=w)[0]
+            base.append(bucket_rows(ev_full, cfg, b, e))
+            # the WINDOW's reference time (feature_detector.cpp:305-306): from its first / last event,
+            # known to whoever cut the window; a shard cannot derive it from its own events
+            base_tref.append(ebo.window_ref_time(ev_full["t_us"][0], ev_full["t_us"][-1]))
+            del ev_full
+        evs, cnts, t_ref = [], [], []
         for w in range(windows_total):
             ev_w, c_w = base[w % len(base)]
             evs.append(ev_w)
             cnts.append(c_w)
+            t_ref.append(base_tref[w % len(base)])
         ev = np.concatenate(evs) if evs else np.zeros(0, dtype=ebo.EVENT_DTYPE)
         offs = np.zeros(windows_total * len(my_rects) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum(np.concatenate(cnts))
@@ -391,13 +444,31 @@ def main():
         counts = [windows_total * q * npx for q in rows]
         d_all = torch.zeros((sum(counts), 2), dtype=torch.float64, device="cuda")
         n_ev_unit = np.diff(offs.astype(np.int64))
+        # the final image: flows of ALL patches in patch order [window][P][2], partial image [window][H][W]
+        d_grid = torch.zeros((windows_total, npx * npy, 2), dtype=torch.float64, device="cuda")
+        d_img = torch.zeros((windows_total, ih, iw), dtype=torch.float64, device="cuda") if not args.no_c4_image else None
         return dict(cfg=cfg, ctx=ctx, d_sol=d_sol, d_stats=d_stats, d_all=d_all, counts=counts, rows=rows,
+                    t_ref=np.array(t_ref, dtype=np.int64), d_grid=d_grid, d_img=d_img,
                     n_units=n_units, n_ev_unit=n_ev_unit, n_events=len(ev), npx=npx, npy=npy,
                     windows_total=windows_total, opts=ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
 
     def c4_event_evals(S):
         st = S["d_stats"].cpu().numpy()
         return float(((st[:, 1] + st[:, 2]).astype(np.int64) * S["n_ev_unit"]).sum())
+
+    def c4_image(S_):
+        """rank-major gathered blocks [rank][window][its rows][px] -> patch order [window][P][2], then the
+        partial final image of this rank's events and ONE reduce onto rank 0"""
+        at = 0
+        col = 0
+        for q, cnt_q in enumerate(S_["counts"]):
+            nq = S_["rows"][q] * S_["npx"]
+            if nq:
+                S_["d_grid"][:, col:col + nq].copy_(S_["d_all"][at:at + cnt_q].view(S_["windows_total"], nq, 2))
+            at += cnt_q
+            col += nq
+        S_["ctx"].count_image_shard_device(S_["windows_total"], S_["t_ref"], S_["d_grid"].data_ptr(), S_["d_img"].data_ptr())
+        comm.reduce_sum_to_rank0(S_["d_img"])
 
     extras = {}
     roof_kernel = None
@@ -467,6 +538,8 @@ def main():
         def step():
             solve_only()
             comm.allgather_rows(exchange, S["d_sol"], S["counts"], S["d_all"])
+            if S["d_img"] is not None:
+                c4_image(S)
 
         step()
         torch.cuda.synchronize()
@@ -477,9 +550,12 @@ def main():
                   "windows_in_batch": wt, "grid_rows_per_gpu": S["rows"], "patches_per_gpu_per_step": S["n_units"],
                   "events_per_gpu_per_step": S["n_events"], "event_evaluations_per_gpu_per_step": units_per_step,
                   "loss": "variance", "grad": "jet",
-                  "step": "device-resident per-patch solve of the shard (ebo_solve_device) + one all-gather of the solved flows",
-                  "parallelism": "patch rows of every window sharded over %d GPU(s), %s all-gather of flows (16 B/patch) per step"
-                                 % (world, "RCCL" if comm.backend == "nccl" else (comm.backend or "no"))}
+                  "step": "device-resident per-patch solve of the shard (ebo_solve_device) + one all-gather of the solved flows"
+                          + ("" if args.no_c4_image else " + partial final count image of the shard's events (ebo_count_image_shard)"
+                             " + one reduce of the images onto rank 0"),
+                  "parallelism": "patch rows of every window sharded over %d GPU(s), %s all-gather of flows (16 B/patch)%s per step"
+                                 % (world, "RCCL" if comm.backend == "nccl" else (comm.backend or "no"),
+                                    "" if args.no_c4_image else " and reduce of the %d x %d f64 images" % (cfg["image"][0], cfg["image"][1]))}
 
     # ---- the timed region: W warm-up steps, barrier, EXACTLY K steps, barrier -----------------
     for _ in range(args.warmup):
@@ -492,6 +568,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = comm.reduce(dt, "MAX")
     total_units = comm.reduce(units_per_step, "SUM")
+    comm_total_events = comm.reduce(float(S["n_events"]), "SUM") if workload == "c4" else None
 
     # ---- dominant kernel: average launch duration by HIP events on ITS stream -----------------
     kern_ms = timed(kernel_fn, max(3, args.steps))
@@ -508,6 +585,12 @@ def main():
         extras["allgather_check"] = bool(np.array_equal(got[lo:lo + len(mine)], mine)) and bool(np.isfinite(got).all())
         st = S["d_stats"].cpu().numpy()
         extras["mean_evals_per_patch"] = float((st[:, 1] + st[:, 2])[st[:, 2] > 0].mean())
+        if S["d_img"] is not None:
+            img = S["d_img"].cpu().numpy()
+            # every event of every window of the batch lands at most once: integer-valued, sum <= events
+            extras["final_image"] = {"windows": int(img.shape[0]), "integer_valued": bool(np.array_equal(img, np.round(img))),
+                                     "events_counted": float(img.sum()),
+                                     "events_in_batch": float(comm_total_events) if comm_total_events is not None else None}
 
     if cpu_all is not None:
         extras["cpu_baseline_all_cores"] = cpu_all
@@ -604,6 +687,19 @@ def main():
                 cx.eval_device(fx.data_ptr(), 1, ox.data_ptr())
             msx = timed(lambda: cx.eval_device(fx.data_ptr(), 1, ox.data_ptr()), reps)
             extras[label] = {"ms": msx, "windows": wn, "patches_per_window": cx.P, "mevents_per_s": rate(len(evx), msx)}
+            if loss == ebo.LOSS_EDGE:
+                # the roofline of the reference's ACTIVE loss: f64 vector arithmetic (not HBM, not MFMA).  The
+                # work is counted by the kernel itself in one extra evaluation (ebo_edge_work_stats)
+                msv = timed(lambda: cx.eval_device(fx.data_ptr(), 0, ox.data_ptr()), reps)
+                st = cx.edge_work_stats(fx.data_ptr(), True)
+                fj, fv = edge_flops(st, True), edge_flops(st, False)
+                extras[label]["value_only_ms"] = msv
+                extras[label]["edge_roofline"] = {
+                    "bound": "f64 vector ALU", "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "work": st,
+                    "flops_per_item": EDGE_FLOPS, "useful_flops_with_jacobian": fj, "useful_flops_value_only": fv,
+                    "achieved_with_jacobian": fj / (msx * 1e-3) / 1e12, "achieved_value_only": fv / (msv * 1e-3) / 1e12,
+                    "frac_with_jacobian": fj / (msx * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                    "frac_value_only": fv / (msv * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS}
             cx.close()
 
         # the other BASELINE sizes with the same kernel, and the reference's own default objective
@@ -614,6 +710,26 @@ def main():
         eval_extra(3, 16, ebo.LOSS_EDGE, "edge_loss_value_jacobian_c3")
         rcfg = dict(name="reference default", image=(240, 180), patch=(20, 20), events=15000, index=0)
         eval_extra(0, 256, ebo.LOSS_EDGE, "edge_loss_value_jacobian_reference_default", cfgd=rcfg)
+
+        # the per-patch (TV-free) solve with the reference's own loss: device-resident (k_solve_edge, the
+        # default) against host LMs in lock step over batched evaluations, 256 reference-default windows
+        evs_, offs_, _ = synth.make_stream(rcfg, 256)
+        ce = ebo.Context(device=dev, image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE, tv_weight=0.0,
+                         max_events=len(evs_), max_windows=256)
+        ce.set_windows(evs_, offs_)
+        es = {}
+        for how in ("device", "lockstep"):
+            os.environ["EBO_SOLVE_EDGE"] = how
+            ce.solve(ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
+            t0 = time.perf_counter()
+            _, ss_ = ce.solve(ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
+            es[how + "_ms"] = (time.perf_counter() - t0) * 1e3
+        os.environ.pop("EBO_SOLVE_EDGE")
+        es["windows"] = 256
+        es["evaluations_window0"] = int(ss_[0].num_evals_cost + ss_[0].num_evals_jac)
+        extras["edge_solve_independent_reference_default"] = es
+        ce.close()
+        del evs_, offs_
 
         # integer count images (the HBM-bound kernels) on working sets >= 1 GiB: a few distinct
         # windows repeated (every copy has its own events and its own image in HBM)
@@ -641,6 +757,13 @@ def main():
                 msx = min(timed(lambda: cx.count_image_device(mode, aux, d_img.data_ptr()), 10) for _ in range(3))
                 res[name] = {"ms": msx, "mevents_per_s": rate(n_ev, msx), "gbs_algorithmic": nbytes / (msx * 1e-3) / 1e9,
                              "hbm_frac": nbytes / (msx * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # same-run yardstick: the same bytes (events read once + image written once) with no work
+            moved = cx.stream_yardstick_device(d_img.data_ptr())
+            msy = min(timed(lambda: cx.stream_yardstick_device(d_img.data_ptr()), 10) for _ in range(3))
+            res["plain_stream_same_bytes"] = {"ms": msy, "gbs": moved / (msy * 1e-3) / 1e9,
+                                              "hbm_frac": moved / (msy * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            for name in ("warped", "integrated"):
+                res[name]["frac_of_plain_stream"] = msy / res[name]["ms"]
             extras[label] = res
             cx.close()
             del d_img, fl
@@ -656,6 +779,8 @@ def main():
         def c4_step():
             S4["ctx"].solve_device(S4["opts"], S4["d_sol"].data_ptr(), S4["d_stats"].data_ptr())
             S4["d_all"].copy_(S4["d_sol"])
+            if S4["d_img"] is not None:
+                c4_image(S4)
 
         c4_step()
         ms4 = timed(c4_step, 5)
@@ -688,6 +813,8 @@ def main():
             t1_ = time.perf_counter() - t0
             t_one = t1_ if t_one is None else min(t_one, t1_)
         cr1.close()
+        if "edge_loss_value_jacobian_reference_default" in extras:
+            extras["edge_roofline"] = extras["edge_loss_value_jacobian_reference_default"].get("edge_roofline")
         extras["reference_default_call"] = {"windows": 64, "ms_per_window": t_ref * 1e3 / 64,
                                             "iterations": rs[0].iterations, "ms_single_window": t_one * 1e3}
         # per-feature tracker objective (Optimizer::optimize's solve), 100 tracked 25x25 patches
@@ -711,7 +838,7 @@ def main():
         co.close()
 
     if rank == 0:
-        base = cpu_baseline(synth, args.config if workload != "c4" else 3, args.cpu_seconds) if world == 1 else None
+        base = cpu_baseline(synth, args.config if workload != "c4" else 3, args.cpu_seconds) if world == 1 else base_early
         # HBM traffic of the dominant kernel per launch, from the committed PMC profile of
         # this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)
         traffic, traffic_src = None, None

@@ -457,6 +457,19 @@ class Context:
         self._check(lib().ebo_count_image_shard_device(self._h, int(n_windows), _vp(t_ref),
                                                        C.c_void_p(int(d_flows_grid)), C.c_void_p(int(d_image))))
 
+    def edge_work_stats(self, d_flows, want_jac=True):
+        """diagnostic: one edge-loss evaluation that counts its work -> dict of totals over the units"""
+        out = (C.c_uint64 * 6)()
+        self._check(lib().ebo_edge_work_stats(self._h, C.c_void_p(int(d_flows)), 1 if want_jac else 0, out))
+        keys = ("units", "events", "box_pixels", "eigen_pixels", "nms_windows", "argmax_entries")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def stream_yardstick_device(self, d_image):
+        """diagnostic: the bytes of a count-image launch with no work; returns the bytes moved"""
+        n = C.c_uint64()
+        self._check(lib().ebo_stream_yardstick_device(self._h, C.c_void_p(int(d_image)), C.byref(n)))
+        return n.value
+
     def count_image_device(self, mode, d_aux, d_image):
         self._check(lib().ebo_count_image_device(
             self._h, int(mode), C.c_void_p(int(d_aux)) if d_aux else None,

@@ -378,6 +378,7 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 			L.ec.cs = c->d_edge_cs;
 		}
 	}
+	L.ec.stats = nullptr;
 	L.ec.mean_threshold = 0.0001;
 	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
 	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 7));  // forms of the separable tensor filter (see EdgeConsts / ebo_edge.inc)
@@ -399,6 +400,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	{
 		return rc;
 	}
+	L.ec.stats = c->edge_stats_dev;  // non-null only inside ebo_edge_work_stats
 	if (launch_eval_edge(L, c->stream))
 	{
 		return c->hip(hipGetLastError(), "edge eval launch");
@@ -1349,13 +1351,15 @@ int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_o
 {
 	// device-resident per-patch LM for both losses (forward-mode-equivalent Jacobians);
 	// central differences and EBO_SOLVE_EDGE=lockstep (A/B) run host LMs over batched evaluations
-	// Edge loss, measured (tools/time_edge_solve.py): one reference-default window 3.5 ms on the
-	// device against 5.2 ms in lock step (67 evaluations = 67 round trips); 256 windows 198 against
-	// 194 ms; C2 x 64 windows 81 against 66-72 ms (the batched value-only kernel is the faster one and
-	// the hardware balances uneven patches).  So: the device solve below 2048 units, lock step above;
-	// EBO_SOLVE_EDGE=device / lockstep forces one.  ebo_solve_device is always the device solve.
+	// Edge loss, measured (tools/time_edge_solve.py, round 3: solver state in LDS, the LM on one lane,
+	// spill-free instantiations): one reference-default window 2.1 ms on the device against 4.3 ms in
+	// lock step (67 evaluations = 67 round trips); 256 windows 78 against 161-172 ms; C2 x 64 windows 33
+	// against 61-65 ms; C3 x 16 windows 21 against 44 ms.  The device solve at every size (round 2 lost
+	// to lock step from 2048 units up: its solver ran replicated in every wave and cost the workgroup
+	// as many vector instructions as the evaluations themselves).  EBO_SOLVE_EDGE=lockstep forces the
+	// host LMs (A/B); ebo_solve_device is always the device solve.
 	const char* edgeMode = std::getenv("EBO_SOLVE_EDGE");
-	bool lockstepEdge = c->prm.loss == EBO_LOSS_EDGE && c->n_flows() >= 2048;
+	bool lockstepEdge = false;
 	if (c->prm.loss == EBO_LOSS_EDGE && edgeMode && *edgeMode)
 	{
 		lockstepEdge = std::strcmp(edgeMode, "lockstep") == 0;
@@ -1934,6 +1938,86 @@ int ebo_count_image_device(ebo_ctx* c, int mode, const void* d_aux, double* d_im
 		return c->fail(EBO_ERR_STATE, "no window loaded");
 	}
 	return count_device(c, mode, d_aux, d_image);
+}
+
+int ebo_edge_work_stats(ebo_ctx* c, const double* d_flows, int want_jac, uint64_t* out)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!d_flows || !out)
+	{
+		return c->fail(EBO_ERR_ARG, "null pointer");
+	}
+	if (c->prm.loss != EBO_LOSS_EDGE || c->n_windows == 0)
+	{
+		return c->fail(EBO_ERR_STATE, "needs the edge loss and a loaded window");
+	}
+	(void)hipSetDevice(c->prm.device);
+	int rc = ensure_aux(c, 6 * sizeof(unsigned long long));
+	if (rc)
+	{
+		return rc;
+	}
+	rc = c->hip(hipMemsetAsync(c->d_aux, 0, 6 * sizeof(unsigned long long), c->stream), "zero edge stats");
+	if (rc)
+	{
+		return rc;
+	}
+	c->edge_stats_dev = static_cast<unsigned long long*>(c->d_aux);
+	rc = run_eval_device(c, d_flows, want_jac, c->d_out);
+	c->edge_stats_dev = nullptr;
+	if (rc)
+	{
+		return rc;
+	}
+	unsigned long long h[6];
+	rc = c->hip(hipMemcpyAsync(h, c->d_aux, sizeof(h), hipMemcpyDeviceToHost, c->stream), "D2H edge stats");
+	if (rc == EBO_OK)
+	{
+		rc = c->hip(hipStreamSynchronize(c->stream), "sync");
+	}
+	for (int k = 0; k < 6 && rc == EBO_OK; ++k)
+	{
+		out[k] = h[k];
+	}
+	return rc;
+}
+
+int ebo_stream_yardstick_device(ebo_ctx* c, double* d_image, uint64_t* bytes)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!d_image)
+	{
+		return c->fail(EBO_ERR_ARG, "null image");
+	}
+	if (c->n_windows == 0 || c->custom_n)
+	{
+		return c->fail(EBO_ERR_STATE, "no window loaded");
+	}
+	size_t nEv = 0;
+	for (const WindowInfo& wi : c->windows)
+	{
+		nEv += wi.n_events;
+	}
+	const size_t nPx = static_cast<size_t>(c->n_windows) * c->prm.image_w * c->prm.image_h;
+	if ((reinterpret_cast<uintptr_t>(d_image) & 15) != 0)
+	{
+		return c->fail(EBO_ERR_ARG, "image must be 16-byte aligned");
+	}
+	if (bytes)
+	{
+		*bytes = (nEv / 2) * 16 + (nPx / 2) * 16;
+	}
+	if (launch_stream_yardstick(c->d_events, nEv, d_image, nPx, c->stream))
+	{
+		return c->fail(EBO_ERR_HIP, "k_stream_yardstick launch failed");
+	}
+	return EBO_OK;
 }
 
 int ebo_window_ref_time(int64_t t_first_us, int64_t t_last_us, int64_t* t_ref_us)

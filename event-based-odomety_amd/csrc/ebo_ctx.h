@@ -87,6 +87,7 @@ struct ebo_ctx
 	size_t scratch_cap = 0;
 	double* d_edge_w = nullptr;      // the 49 tensor weights of the edge loss (device table)
 	double edge_w_sigma = -1.0;      // sigma_st they were built for
+	unsigned long long* edge_stats_dev = nullptr;  // set only while ebo_edge_work_stats runs its one evaluation
 	double* d_edge_cs = nullptr;     // eigenvector directions of the edge loss's eigenvalue pass, [unit][cap_px][2]
 	size_t edge_cs_cap = 0;          // bytes
 	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays

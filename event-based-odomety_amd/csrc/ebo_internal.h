@@ -117,6 +117,7 @@ struct EdgeConsts
 	double* cs;            // DEVICE table [unit][cap_px][2] or null: (s00 - s11)/d and 2 s01/d of every pixel with a positive eigenvalue, written by the eigenvalue pass of a Jacobian evaluation, read by its reverse pass for the argmax pixels (null: the reverse pass re-derives the tensor sums)
 	int cs_stride;         // pixels per unit in cs (= cap_px)
 	int reserved;          // tensor filter forms (EBO_EDGE_SEPARABLE): 1 band buffers on the 28 B layout, 2 register runs on the 20 B layout, 4 register runs on the 28 B layout
+	unsigned long long* stats;  // null, or DEVICE counters [6] of ebo_edge_work_stats: units past the penalty test, their events, box pixels, eigenvalue-region pixels, NMS windows, argmax entries
 };
 
 struct EdgeLaunch
@@ -141,6 +142,7 @@ struct EdgeLaunch
 	EvalConsts c;
 	EdgeConsts ec;
 };
+int launch_stream_yardstick(const uint64_t* d_events, size_t n_events, double* d_image, size_t n_pixels, void* stream);
 int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,
 					   const int32_t* d_dtwin, const double* d_flows, double* d_image, const EvalConsts& c, void* stream);
 int launch_eval_edge(const EdgeLaunch& L, void* stream);

@@ -2094,6 +2094,34 @@ __global__ void k_count_stray(const uint64_t* __restrict__ events, const Unit* _
 	}
 }
 
+// Yardstick of the count-image kernels (bench.py, diagnostic): the same bytes with no work -- every packed
+// event read once with 16-byte loads, every image pixel written once with 16-byte stores -- by 2048
+// workgroups that each take a contiguous slice of both.  What this reaches on the chip is what "100 %"
+// means for a kernel of that traffic (the loads are kept alive by an XOR the compiler must produce).
+__global__ void __launch_bounds__(256) k_stream_yardstick(const uint4* __restrict__ events16, size_t nEv16,
+														   double2* __restrict__ image16, size_t nPx16)
+{
+	const size_t perE = (nEv16 + gridDim.x - 1) / gridDim.x, perP = (nPx16 + gridDim.x - 1) / gridDim.x;
+	const size_t e0 = perE * blockIdx.x, e1 = min(e0 + perE, nEv16);
+	unsigned int x = 0;
+	for (size_t i = e0 + threadIdx.x; i < e1; i += 4 * blockDim.x)
+	{
+		// four independent 16-byte loads in flight per lane
+		const uint4 a = events16[i];
+		const uint4 b = (i + blockDim.x < e1) ? events16[i + blockDim.x] : make_uint4(0, 0, 0, 0);
+		const uint4 c = (i + 2 * blockDim.x < e1) ? events16[i + 2 * blockDim.x] : make_uint4(0, 0, 0, 0);
+		const uint4 d = (i + 3 * blockDim.x < e1) ? events16[i + 3 * blockDim.x] : make_uint4(0, 0, 0, 0);
+		x ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+	}
+	asm volatile("" ::"v"(x));  // the loads are used
+	const double v = 0.0;
+	const size_t p0 = perP * blockIdx.x, p1 = min(p0 + perP, nPx16);
+	for (size_t i = p0 + threadIdx.x; i < p1; i += blockDim.x)
+	{
+		image16[i] = make_double2(v, v);
+	}
+}
+
 // The final image of warped events (feature_detector.cpp:433-463) of windows whose patches are SHARDED
 // over ranks (BASELINE config 4): the context holds, per window, the units of this rank's
 // patch rows (ebo_set_patches), `flows` are those of ALL patches of the grid (after the all-gather of
@@ -3291,6 +3319,14 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 	Rec24 r;
 	r.p = static_cast<const RawEvent*>(L.d_raw);
 	return launch_bucket_t(L, r, s);
+}
+
+int launch_stream_yardstick(const uint64_t* d_events, size_t n_events, double* d_image, size_t n_pixels, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	hipLaunchKernelGGL(k_stream_yardstick, dim3(2048), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_events), n_events / 2,
+					   reinterpret_cast<double2*>(d_image), n_pixels / 2);
+	return check_launch();
 }
 
 int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,

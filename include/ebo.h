@@ -326,6 +326,20 @@ int ebo_route_events(ebo_ctx* ctx, int n_patches, const double* rects, const uin
 					 const uint32_t* max_take, uint32_t cap, uint32_t* out_index, uint32_t* out_count,
 					 uint32_t* out_next);
 
+/* Diagnostic (bench.py's edge_roofline): ONE evaluation of the edge loss at d_flows (device, [Wn][P][2]) that
+ * also counts the work it is made of, summed over the units that pass the empty-window test of
+ * contrast_functor.h:159-165 -- out[0] units, [1] their events, [2] pixels of their bounding boxes, [3] pixels
+ * of the eigenvalue region, [4] non-maximum-suppression windows, [5] argmax entries of the reverse pass
+ * (0 without want_jac).  DESIGN.md 4.5 turns them into useful f64 operations.  Synchronous; the
+ * evaluation's (r, J) go to the context's own result buffer. */
+int ebo_edge_work_stats(ebo_ctx* ctx, const double* d_flows, int want_jac, uint64_t* out);
+
+/* Diagnostic (bench.py): the traffic of ebo_count_image_device with no work -- every packed event of the
+ * loaded windows read once (16-byte loads), every pixel of d_image [Wn][image_h][image_w] written once
+ * (16-byte stores, all 0.0) -- as the in-run yardstick of the HBM-bound count kernels: what a plain stream
+ * of these bytes reaches on this GPU.  *bytes (may be NULL) receives the bytes moved.  Asynchronous. */
+int ebo_stream_yardstick_device(ebo_ctx* ctx, double* d_image, uint64_t* bytes);
+
 /* R2's final loop (:433-463) for windows whose PATCHES ARE SHARDED over ranks (BASELINE
  * config 4).  The context was loaded by ebo_set_patches with n_windows equal groups of units (group w =
  * this rank's patches of window w with the events inside them); flows_grid [n_windows][P][2] are the flows
