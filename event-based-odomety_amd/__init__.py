@@ -567,6 +567,23 @@ class Context:
         self._check(lib().ebo_estimate_num_events(self._h, n, _dp(rects), _dp(poses), _dp(flow_dirs), _vp(out)))
         return out[:n]
 
+    def patch_warp_image(self, rects, poses, flow_dirs):
+        """Patch::warpImage for n tracked patches: -> list of predictedNabla arrays [h][w] (None where the
+        reference returns early because the rect touches the image border)."""
+        rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
+        flow_dirs = np.ascontiguousarray(flow_dirs, dtype=np.float64).reshape(-1)
+        n = len(rects)
+        shapes = [(int(np.rint(r[3])), int(np.rint(r[2]))) for r in rects]
+        sizes = [h * w for h, w in shapes]
+        noff = np.zeros(max(n, 1), dtype=np.uint64)
+        noff[1:n] = np.cumsum(sizes[:-1])
+        out = np.zeros(max(int(sum(sizes)), 1))
+        upd = np.zeros(max(n, 1), dtype=np.int32)
+        self._check(lib().ebo_patch_warp_image(self._h, n, _dp(rects), _dp(poses), _dp(flow_dirs), _vp(noff), _dp(out),
+                                               _vp(upd)))
+        return [out[int(noff[i]):int(noff[i]) + sizes[i]].reshape(shapes[i]).copy() if upd[i] else None for i in range(n)]
+
     # -- tracked-feature patches (Patch::integrate*) --------------------------
     def patch_integrate(self, ev, offsets, rects):
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)

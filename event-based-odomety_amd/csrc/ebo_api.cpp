@@ -3,6 +3,7 @@
 // There is no CPU compute path here: every objective value, Jacobian, solved flow
 // and count image comes from the HIP kernels in ebo_kernels.hip.
 #include "ebo_ctx.h"
+#include "lockstep.h"
 
 #include <atomic>
 #include <chrono>
@@ -685,154 +686,61 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 	return EBO_OK;
 }
 
-// A small thread pool for the host side of lock-step solves: the per-window LM state machines
-// are independent, and with hundreds of windows their linear algebra is what bounds a round
-// (measured: 256 windows of the reference configuration, 10 us per window-round).  The pool
-// lives for ONE solve call (threads are created when the call has enough independent problems
-// and joined before it returns): no thread of this library outlives an API call, so process
-// exit, dlclose and profilers that wrap the process never meet a parked worker.
-// A round's work is tens of microseconds per thread and rounds follow each other every ~100 us, so
-// waking parked workers through a condition variable (30-50 us) was most of a round's host time
-// (64 reference-default windows: 9.7 of 17.6 ms in the LM steps): workers and the caller SPIN on an
-// atomic for EBO_HOST_SPIN_US microseconds (default 200) before they park.
-class HostPool
+// The device behind the lock-step drivers of lockstep.h (which are free of HIP and run under the
+// sanitizers on the CPU with another backend).
+struct CtxLockstepBackend
 {
-   public:
-	// problems: independent state machines of the call; perThread: how many make a thread worth it
-	HostPool(size_t problems, size_t perThread)
+	explicit CtxLockstepBackend(ebo_ctx* ctx) : c(ctx) {}
+	int eval(const double* flows, double* r, double* J, const unsigned char* modes) { return eval_host(c, flows, r, J, modes); }
+	bool pipelined(int windows, size_t slots) const
 	{
-		unsigned hw = std::thread::hardware_concurrency();
-		const char* v = std::getenv("EBO_HOST_THREADS");
-		size_t want = v ? static_cast<size_t>(std::max(1, std::atoi(v))) : std::min<size_t>(hw ? hw : 1, 16);
-		want = std::min(want, std::max<size_t>(1, problems / std::max<size_t>(1, perThread)));
-		spinUs_ = static_cast<long>(env_size("EBO_HOST_SPIN_US", 200));
-		for (size_t i = 1; i < want; ++i)
-		{
-			workers_.emplace_back([this] { run(); });
-		}
+		return windows >= 16 && slots > env_size("EBO_ZERO_COPY_MAX", 4096) && !std::getenv("EBO_SOLVE_NO_PIPELINE");
 	}
-	// fn(begin, end) over [0, n) in contiguous chunks; the caller works too.
-	template <class F>
-	void parallel_for(size_t n, size_t minPerThread, F&& fn)
+	int groups() const { return static_cast<int>(env_size("EBO_SOLVE_GROUPS", 2)); }
+	int pipeline_begin(size_t slots, int G)
 	{
-		const size_t maxT = workers_.size() + 1;
-		size_t T = std::min(maxT, std::max<size_t>(1, n / std::max<size_t>(1, minPerThread)));
-		if (T <= 1)
+		int rc = ensure_eval_staging(c, slots);
+		if (rc == EBO_OK) rc = ensure_device_modes(c, slots);
+		if (rc)
 		{
-			fn(static_cast<size_t>(0), n);
-			return;
+			return rc;
 		}
-		std::function<void(size_t, size_t)> f = fn;
-		const size_t chunk = (n + T - 1) / T;
+		for (int g = 0; g < G; ++g)
 		{
-			std::unique_lock<std::mutex> lk(mu_);
-			job_ = &f;
-			n_ = n;
-			chunk_ = chunk;
-			next_ = 1;  // chunk 0 is the caller's
-			chunks_ = T;
-			pending_.store(T - 1, std::memory_order_relaxed);
-			++generation_;
-			published_.store(generation_, std::memory_order_release);
-		}
-		cv_.notify_all();
-		fn(static_cast<size_t>(0), std::min(n, chunk));
-		spin_until([&] { return pending_.load(std::memory_order_acquire) == 0; });
-		std::unique_lock<std::mutex> lk(mu_);
-		done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
-		job_ = nullptr;
-	}
-
-	HostPool(const HostPool&) = delete;
-	HostPool& operator=(const HostPool&) = delete;
-	~HostPool()
-	{
-		{
-			std::unique_lock<std::mutex> lk(mu_);
-			stop_ = true;
-			published_.store(~static_cast<size_t>(0), std::memory_order_release);  // ends the spinning
-		}
-		cv_.notify_all();
-		for (auto& t : workers_)
-		{
-			t.join();
-		}
-	}
-   private:
-	template <class P>
-	void spin_until(P&& ready) const
-	{
-		if (spinUs_ <= 0 || ready())
-		{
-			return;
-		}
-		const auto t0 = std::chrono::steady_clock::now();
-		for (;;)
-		{
-			for (int i = 0; i < 32; ++i)
+			if (hipEventCreateWithFlags(&done[g], hipEventDisableTiming) != hipSuccess)
 			{
-				if (ready())
+				for (int k = 0; k < g; ++k)
 				{
-					return;
+					(void)hipEventDestroy(done[k]);
+					done[k] = nullptr;
 				}
-#if defined(__x86_64__) || defined(__i386__)
-				__builtin_ia32_pause();
-#endif
-			}
-			if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spinUs_)
-			{
-				return;
+				return c->fail(EBO_ERR_HIP, "hipEventCreate");
 			}
 		}
+		return EBO_OK;
 	}
-	void run()
+	void pipeline_end(int G)
 	{
-		size_t seen = 0;  // the last generation this worker has nothing more to do for
-		for (;;)
+		(void)hipStreamSynchronize(c->stream);
+		for (int g = 0; g < G; ++g)
 		{
-			spin_until([&] { return published_.load(std::memory_order_acquire) != seen; });
-			std::function<void(size_t, size_t)>* job = nullptr;
-			size_t b = 0, e = 0;
+			if (done[g])
 			{
-				std::unique_lock<std::mutex> lk(mu_);
-				cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
-				if (stop_)
-				{
-					return;
-				}
-				if (!job_ || next_ >= chunks_)
-				{
-					seen = generation_;  // every chunk of this generation has been taken
-					continue;
-				}
-				const size_t k = next_++;
-				if (next_ >= chunks_)
-				{
-					seen = generation_;
-				}
-				job = job_;
-				b = k * chunk_;
-				e = std::min(n_, b + chunk_);
-			}
-			if (b < e)
-			{
-				(*job)(b, e);
-			}
-			if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1)
-			{
-				std::unique_lock<std::mutex> lk(mu_);
-				done_.notify_all();
+				(void)hipEventDestroy(done[g]);
+				done[g] = nullptr;
 			}
 		}
 	}
-	std::vector<std::thread> workers_;
-	std::mutex mu_;
-	std::condition_variable cv_, done_;
-	std::function<void(size_t, size_t)>* job_ = nullptr;
-	size_t n_ = 0, chunk_ = 0, next_ = 0, chunks_ = 0, generation_ = 0;
-	std::atomic<size_t> pending_{0}, published_{0};
-	long spinUs_ = 200;
-	bool stop_ = false;
+	int eval_begin(const double* flows, const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac)
+	{
+		return ebo_host::eval_begin(c, flows, modes, g, s0, s1, wantJac, done[g]);
+	}
+	int eval_finish(const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, double* r, double* J)
+	{
+		return ebo_host::eval_finish(c, modes, s0, s1, wantJac, r, J, done[g]);
+	}
+	ebo_ctx* c;
+	hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 SolveConsts make_solve_consts(const ebo_solver_opts* o)
@@ -1047,195 +955,11 @@ int solve_global(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_su
 		lm.emplace_back(c->npx, c->npy, active, c->prm.tv_weight, c->prm.tv_huber, *o);
 	}
 	std::vector<double> flows(static_cast<size_t>(Wn) * P * 2, 0.0);
-	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
-	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
-	// (with spinning workers a thread pays off from two windows' LM steps up: 64 windows, 17.2 -> see DESIGN 4.3)
-	HostPool pool(static_cast<size_t>(Wn), 2);
-	// EBO_SOLVE_TRACE=1: where a lock-step solve spends its time (stderr, one line per call)
-	const bool trace = std::getenv("EBO_SOLVE_TRACE") != nullptr;
-	double tReq = 0.0, tEval = 0.0, tSup = 0.0;
-	int rounds = 0;
-	auto now = [] { return std::chrono::steady_clock::now(); };
-	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-		return std::chrono::duration<double, std::milli>(b - a).count();
-	};
-	// Many windows: two halves in flight.  While the device evaluates one half, the host takes the
-	// other half's results, runs its LM steps and asks for its next points -- with 256 windows of
-	// the reference configuration the host side (16 ms of LM steps and requests per solve) had
-	// grown to half of the wall time once the kernels got faster.  Per window the sequence of
-	// requests and evaluations is unchanged: same results.
-	const size_t nfAll = static_cast<size_t>(Wn) * P;
-	if (Wn >= 16 && nfAll > env_size("EBO_ZERO_COPY_MAX", 4096) && !std::getenv("EBO_SOLVE_NO_PIPELINE"))
+	CtxLockstepBackend backend(c);
+	const int rcl = lockstep_global(backend, Wn, P, lm, flows, std::getenv("EBO_SOLVE_TRACE") != nullptr);
+	if (rcl)
 	{
-		int rc = ensure_eval_staging(c, nfAll);
-		if (rc == EBO_OK) rc = ensure_device_modes(c, nfAll);
-		if (rc)
-		{
-			return rc;
-		}
-		constexpr int kMaxGroups = 4;
-		const int G = static_cast<int>(std::min<size_t>(std::max<size_t>(env_size("EBO_SOLVE_GROUPS", 2), 2), kMaxGroups));
-		hipEvent_t done[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
-		for (int g = 0; g < G; ++g)
-		{
-			if (hipEventCreateWithFlags(&done[g], hipEventDisableTiming) != hipSuccess)
-			{
-				for (int k = 0; k < g; ++k) (void)hipEventDestroy(done[k]);
-				return c->fail(EBO_ERR_HIP, "hipEventCreate");
-			}
-		}
-		size_t wSplit[kMaxGroups + 1];
-		for (int g = 0; g <= G; ++g)
-		{
-			wSplit[g] = static_cast<size_t>(Wn) * g / G;
-		}
-		std::vector<unsigned char> gmodes[kMaxGroups];
-		for (int g = 0; g < G; ++g)
-		{
-			gmodes[g].assign(nfAll, 0);
-		}
-		bool inflight[kMaxGroups] = {false, false, false, false}, gJac[kMaxGroups] = {false, false, false, false};
-		// request: every window of the half says what it wants next; true if any is still running
-		auto request = [&](int g) {
-			// (a request is a copy of 2 P doubles and a memset: threads only from 64 windows per thread up)
-			pool.parallel_for(wSplit[g + 1] - wSplit[g], 64, [&](size_t b, size_t e) {
-				for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
-				{
-					const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
-					wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
-					std::memset(&gmodes[g][w * P], wmode[w], static_cast<size_t>(P));
-				}
-			});
-			bool any = false;
-			gJac[g] = false;
-			for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
-			{
-				any = any || wmode[w] != 0;
-				gJac[g] = gJac[g] || wmode[w] == 2;
-			}
-			return any;
-		};
-		auto launch = [&](int g) {
-			inflight[g] = true;
-			++rounds;
-			return eval_begin(c, flows.data(), gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g], done[g]);
-		};
-		for (int g = 0; g < G && rc == EBO_OK; ++g)
-		{
-			if (request(g))
-			{
-				rc = launch(g);
-			}
-		}
-		auto anyInflight = [&] { for (int g = 0; g < G; ++g) { if (inflight[g]) return true; } return false; };
-		std::vector<size_t> live;
-		live.reserve(static_cast<size_t>(Wn));
-		while (rc == EBO_OK && anyInflight())
-		{
-			for (int g = 0; g < G && rc == EBO_OK; ++g)
-			{
-				if (!inflight[g])
-				{
-					continue;
-				}
-				const auto t1 = now();
-				rc = eval_finish(c, gmodes[g].data(), wSplit[g] * P, wSplit[g + 1] * P, gJac[g], r.data(), J.data(), done[g]);
-				inflight[g] = false;
-				if (rc)
-				{
-					break;
-				}
-				const auto t2 = now();
-				// the windows of the half that are still running (late in a solve: a few stragglers, which
-				// then do not pay for waking the pool)
-				live.clear();
-				for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
-				{
-					if (wmode[w] != 0)
-					{
-						live.push_back(w);
-					}
-				}
-				pool.parallel_for(live.size(), 2, [&](size_t b, size_t e) {
-					for (size_t k = b; k < e; ++k)
-					{
-						const size_t w = live[k];
-						lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
-					}
-				});
-				const auto t3 = now();
-				const bool more = request(g);
-				tEval += ms(t1, t2);
-				tSup += ms(t2, t3);
-				tReq += ms(t3, now());
-				if (more)
-				{
-					rc = launch(g);
-				}
-			}
-		}
-		(void)hipStreamSynchronize(c->stream);
-		for (int g = 0; g < G; ++g)
-		{
-			(void)hipEventDestroy(done[g]);
-		}
-		if (rc)
-		{
-			return rc;
-		}
-	}
-	else
-	for (;;)
-	{
-		const auto t0 = now();
-		// every window says what it wants next (its own point, value or value + Jacobian);
-		// finished windows drop out of the launch
-		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
-			for (size_t w = b; w < e; ++w)
-			{
-				const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
-				wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
-				std::memset(&modes[w * P], wmode[w], static_cast<size_t>(P));
-			}
-		});
-		bool any = false, anyJac = false, uniform = true;
-		for (int w = 0; w < Wn; ++w)
-		{
-			any = any || wmode[w] != 0;
-			anyJac = anyJac || wmode[w] == 2;
-			uniform = uniform && wmode[w] == wmode[0];
-		}
-		if (!any)
-		{
-			break;
-		}
-		// all windows in the same phase (always so for a single window): no mode table needed
-		const auto t1 = now();
-		int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr, uniform ? nullptr : modes.data());
-		if (rc)
-		{
-			return rc;
-		}
-		const auto t2 = now();
-		pool.parallel_for(static_cast<size_t>(Wn), 2, [&](size_t b, size_t e) {
-			for (size_t w = b; w < e; ++w)
-			{
-				if (wmode[w] != 0)
-				{
-					lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
-				}
-			}
-		});
-		const auto t3 = now();
-		tReq += ms(t0, t1);
-		tEval += ms(t1, t2);
-		tSup += ms(t2, t3);
-		++rounds;
-	}
-	if (trace)
-	{
-		std::fprintf(stderr, "[ebo] lock-step solve: %d windows, %d rounds: request %.2f ms, evaluation (staging + kernels + sync; pipelined: waiting only) %.2f ms, supply (LM steps) %.2f ms\n",
-					 Wn, rounds, tReq, tEval, tSup);
+		return rcl;
 	}
 	int worst = 0;
 	for (int w = 0; w < Wn; ++w)
@@ -1286,43 +1010,12 @@ int solve_independent_lockstep(ebo_ctx* c, const ebo_solver_opts* o, double* flo
 			}
 		}
 	}
-	std::vector<double> flows(nf * 2, 0.0), r(nf), J(nf * 2);
-	std::vector<unsigned char> modes(nf, 0);
-	HostPool pool(lms.size(), 256);
-	for (;;)
+	std::vector<double> flows(nf * 2, 0.0);
+	CtxLockstepBackend backend(c);
+	const int rcl = lockstep_independent(backend, lms, slot, nf, flows);
+	if (rcl)
 	{
-		// every patch says what it wants next; finished patches drop out of the launch
-		pool.parallel_for(lms.size(), 256, [&](size_t b, size_t e) {
-			for (size_t k = b; k < e; ++k)
-			{
-				const HostLm::Request q = lms[k].request(&flows[2 * slot[k]]);
-				modes[slot[k]] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
-			}
-		});
-		bool any = false, anyJac = false;
-		for (size_t k = 0; k < lms.size(); ++k)
-		{
-			any = any || modes[slot[k]] != 0;
-			anyJac = anyJac || modes[slot[k]] == 2;
-		}
-		if (!any)
-		{
-			break;
-		}
-		const int rc = eval_host(c, flows.data(), r.data(), anyJac ? J.data() : nullptr, modes.data());
-		if (rc)
-		{
-			return rc;
-		}
-		pool.parallel_for(lms.size(), 256, [&](size_t b, size_t e) {
-			for (size_t k = b; k < e; ++k)
-			{
-				if (modes[slot[k]] != 0)
-				{
-					lms[k].supply(&r[slot[k]], modes[slot[k]] == 2 ? &J[2 * slot[k]] : nullptr);
-				}
-			}
-		});
+		return rcl;
 	}
 	std::fill(flows_out, flows_out + nf * 2, 0.0);
 	if (summary)

@@ -324,6 +324,9 @@ int launch_optimizer_interleave(const double* d_gx, const double* d_gy, size_t n
 int launch_estimate_num_events(const double2* d_grid, int w, int h, int n, const double* d_rects, const double* d_poses,
 								const double* d_flows, double* d_sums, void* stream);
 
+int launch_patch_warp_image(const double2* d_grid, int w, int h, int n, const double* d_rects, const double* d_poses,
+							const double* d_flows, const int* d_skip, const size_t* d_offsets, double* d_out, void* stream);
+
 struct PatchIntLaunch
 {
 	const uint64_t* d_events;  // packed, dt = mid_time - t

@@ -3235,6 +3235,18 @@ int launch_estimate_num_events(const double2* d_grid, int w, int h, int n, const
 	return check_launch();
 }
 
+int launch_patch_warp_image(const double2* d_grid, int w, int h, int n, const double* d_rects, const double* d_poses,
+							const double* d_flows, const int* d_skip, const size_t* d_offsets, double* d_out, void* stream)
+{
+	if (n <= 0)
+	{
+		return 0;
+	}
+	hipLaunchKernelGGL(k_patch_warp_image, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), d_grid, w, h, n, d_rects,
+					   d_poses, d_flows, d_skip, d_offsets, d_out);
+	return check_launch();
+}
+
 template <class Rec>
 static int launch_bucket_t(const BucketLaunch& L, Rec raw, hipStream_t s)
 {

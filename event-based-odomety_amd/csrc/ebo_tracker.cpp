@@ -406,6 +406,92 @@ int ebo_estimate_num_events(ebo_ctx* c, int n, const double* rects, const double
 	return EBO_OK;
 }
 
+int ebo_patch_warp_image(ebo_ctx* c, int n, const double* rects, const double* poses, const double* flow_dirs,
+						 const size_t* nabla_offsets, double* predicted, int32_t* updated)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (n < 0 || (n && (!rects || !poses || !flow_dirs || !nabla_offsets || !predicted || !updated)))
+	{
+		return c->fail(EBO_ERR_ARG, "null argument");
+	}
+	if (!c->opt_grid_valid)
+	{
+		return c->fail(EBO_ERR_STATE, "no gradient grid: call ebo_optimizer_set_grad first");
+	}
+	if (n == 0)
+	{
+		return EBO_OK;
+	}
+	(void)hipSetDevice(c->prm.device);
+	const size_t nn = static_cast<size_t>(n);
+	// patch.cpp:145-150: a rect that touches the image border leaves predictedNabla_ as it is
+	std::vector<int> skip(nn, 0);
+	std::vector<size_t> off(nn, 0), len(nn, 0);
+	size_t total = 0;
+	for (size_t i = 0; i < nn; ++i)
+	{
+		const double* r = rects + 4 * i;
+		const bool border = r[0] < 0 || r[1] < 0 || r[0] + r[2] >= c->prm.image_w || r[1] + r[3] >= c->prm.image_h;
+		const double w = std::nearbyint(r[2]), h = std::nearbyint(r[3]);
+		if (!(w >= 0 && h >= 0 && w <= 32767 && h <= 32767))  // also NaN
+		{
+			return c->fail(EBO_ERR_RANGE, "patch rect size out of range");
+		}
+		skip[i] = border ? 1 : 0;
+		updated[i] = border ? 0 : 1;
+		off[i] = total;
+		len[i] = border ? 0 : static_cast<size_t>(w) * static_cast<size_t>(h);
+		total += len[i];
+	}
+	if (total == 0)
+	{
+		return EBO_OK;
+	}
+	const size_t head = nn * 9 * sizeof(double) + nn * sizeof(int) + nn * sizeof(size_t);
+	const size_t headAligned = (head + 15) & ~static_cast<size_t>(15);
+	int rc = ensure_scratch(c, headAligned + total * sizeof(double));
+	if (rc)
+	{
+		return rc;
+	}
+	char* base = static_cast<char*>(c->d_scratch);
+	double* dRects = reinterpret_cast<double*>(base);
+	double* dPoses = dRects + 4 * nn;
+	double* dFlows = dPoses + 4 * nn;
+	size_t* dOff = reinterpret_cast<size_t*>(dFlows + nn);
+	int* dSkip = reinterpret_cast<int*>(dOff + nn);
+	double* dOut = reinterpret_cast<double*>(base + headAligned);
+	hipError_t e = hipMemcpyAsync(dRects, rects, 4 * nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dPoses, poses, 4 * nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dFlows, flow_dirs, nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dOff, off.data(), nn * sizeof(size_t), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dSkip, skip.data(), nn * sizeof(int), hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess)
+	{
+		(void)hipStreamSynchronize(c->stream);
+		return c->hip(e, "H2D warpImage arguments");
+	}
+	if (launch_patch_warp_image(c->d_opt_grid, c->prm.image_w, c->prm.image_h, n, dRects, dPoses, dFlows, dSkip, dOff, dOut,
+								c->stream))
+	{
+		(void)hipStreamSynchronize(c->stream);
+		return c->hip(hipGetLastError(), "warpImage launch");
+	}
+	for (size_t i = 0; i < nn && e == hipSuccess; ++i)
+	{
+		if (len[i])
+		{
+			e = hipMemcpyAsync(predicted + nabla_offsets[i], dOut + off[i], len[i] * sizeof(double), hipMemcpyDeviceToHost,
+							   c->stream);
+		}
+	}
+	const hipError_t es = hipStreamSynchronize(c->stream);  // also covers the host vectors of the H2D copies
+	return c->hip(e != hipSuccess ? e : es, "D2H predicted nabla");
+}
+
 namespace
 {
 struct OptBuffers

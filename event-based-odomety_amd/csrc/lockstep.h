@@ -1,0 +1,262 @@
+// lockstep.h -- the host side of the lock-step solves (EBO_SOLVE_GLOBAL; EBO_SOLVE_INDEPENDENT where the
+// device-resident solver is not used): many HostLm state machines advanced together so that every round is
+// ONE batched evaluation of all data terms, the per-window LM steps spread over a HostPool, and -- with
+// many windows -- two (to four) groups of windows pipelined: while the backend evaluates one group the host
+// takes another's results, runs its LM steps and posts its next points.
+//
+// Templates on the BACKEND that evaluates the data terms, so that this file is free of HIP: libebo_hip.so
+// instantiates it with the device (ebo_api.cpp, CtxLockstepBackend), tests/cpp/hostlm_stress.cpp with a CPU
+// objective evaluated on another thread -- the same driver code, run under ThreadSanitizer and
+// AddressSanitizer + UBSan by the CPU test-suite (sanitizers on the CPU build).
+//
+// Backend:
+//   int  eval(const double* flows, double* r, double* J /* may be null */, const unsigned char* modes /* may be null */);
+//        synchronous; modes[i]: 0 skip slot i, 1 value, 2 value + Jacobian (null: all slots, Jacobian iff J)
+//   bool pipelined(int windows, size_t slots);  int groups();
+//   int  pipeline_begin(size_t slots, int groups);  void pipeline_end(int groups);
+//   int  eval_begin(const double* flows, const unsigned char* modes, int group, size_t s0, size_t s1, bool wantJac);
+//        asynchronous: may read flows[2 s0, 2 s1) and modes[0, slots) only until it returns
+//   int  eval_finish(const unsigned char* modes, int group, size_t s0, size_t s1, bool wantJac, double* r, double* J);
+//        waits for that group's round, writes r / J of slots [s0, s1) with a non-zero mode
+#pragma once
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "host_lm.h"
+#include "host_pool.h"
+
+namespace ebo
+{
+// EBO_SOLVE_GLOBAL: lm[w] = window w's problem (P flow slots each); flows: [Wn][P][2] scratch of the rounds.
+template <class Backend>
+int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::vector<double>& flows, bool trace)
+{
+	flows.assign(static_cast<size_t>(Wn) * P * 2, 0.0);
+	std::vector<double> r(static_cast<size_t>(Wn) * P), J(static_cast<size_t>(Wn) * P * 2);
+	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
+	// (with spinning workers a thread pays off from two windows' LM steps up: 64 windows, 17.2 -> see DESIGN 4.3)
+	HostPool pool(static_cast<size_t>(Wn), 2);
+	// trace (EBO_SOLVE_TRACE=1): where a lock-step solve spends its time (stderr, one line per call)
+	double tReq = 0.0, tEval = 0.0, tSup = 0.0;
+	int rounds = 0;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return std::chrono::duration<double, std::milli>(b - a).count();
+	};
+	// Many windows: two halves in flight.  While the device evaluates one half, the host takes the
+	// other half's results, runs its LM steps and asks for its next points -- with 256 windows of
+	// the reference configuration the host side (16 ms of LM steps and requests per solve) had
+	// grown to half of the wall time once the kernels got faster.  Per window the sequence of
+	// requests and evaluations is unchanged: same results.
+	const size_t nfAll = static_cast<size_t>(Wn) * P;
+	if (be.pipelined(Wn, nfAll))
+	{
+		constexpr int kMaxGroups = 4;
+		const int G = std::min(std::max(be.groups(), 2), kMaxGroups);
+		int rc = be.pipeline_begin(nfAll, G);
+		if (rc)
+		{
+			return rc;
+		}
+		size_t wSplit[kMaxGroups + 1];
+		for (int g = 0; g <= G; ++g)
+		{
+			wSplit[g] = static_cast<size_t>(Wn) * g / G;
+		}
+		std::vector<unsigned char> gmodes[kMaxGroups];
+		for (int g = 0; g < G; ++g)
+		{
+			gmodes[g].assign(nfAll, 0);
+		}
+		bool inflight[kMaxGroups] = {false, false, false, false}, gJac[kMaxGroups] = {false, false, false, false};
+		// request: every window of the half says what it wants next; true if any is still running
+		auto request = [&](int g) {
+			// (a request is a copy of 2 P doubles and a memset: threads only from 64 windows per thread up)
+			pool.parallel_for(wSplit[g + 1] - wSplit[g], 64, [&](size_t b, size_t e) {
+				for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
+				{
+					const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
+					wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+					std::memset(&gmodes[g][w * P], wmode[w], static_cast<size_t>(P));
+				}
+			});
+			bool any = false;
+			gJac[g] = false;
+			for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
+			{
+				any = any || wmode[w] != 0;
+				gJac[g] = gJac[g] || wmode[w] == 2;
+			}
+			return any;
+		};
+		auto launch = [&](int g) {
+			inflight[g] = true;
+			++rounds;
+			return be.eval_begin(flows.data(), gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g]);
+		};
+		for (int g = 0; g < G && rc == EBO_OK; ++g)
+		{
+			if (request(g))
+			{
+				rc = launch(g);
+			}
+		}
+		auto anyInflight = [&] { for (int g = 0; g < G; ++g) { if (inflight[g]) return true; } return false; };
+		std::vector<size_t> live;
+		live.reserve(static_cast<size_t>(Wn));
+		while (rc == EBO_OK && anyInflight())
+		{
+			for (int g = 0; g < G && rc == EBO_OK; ++g)
+			{
+				if (!inflight[g])
+				{
+					continue;
+				}
+				const auto t1 = now();
+				rc = be.eval_finish(gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g], r.data(), J.data());
+				inflight[g] = false;
+				if (rc)
+				{
+					break;
+				}
+				const auto t2 = now();
+				// the windows of the half that are still running (late in a solve: a few stragglers, which
+				// then do not pay for waking the pool)
+				live.clear();
+				for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
+				{
+					if (wmode[w] != 0)
+					{
+						live.push_back(w);
+					}
+				}
+				pool.parallel_for(live.size(), 2, [&](size_t b, size_t e) {
+					for (size_t k = b; k < e; ++k)
+					{
+						const size_t w = live[k];
+						lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
+					}
+				});
+				const auto t3 = now();
+				const bool more = request(g);
+				tEval += ms(t1, t2);
+				tSup += ms(t2, t3);
+				tReq += ms(t3, now());
+				if (more)
+				{
+					rc = launch(g);
+				}
+			}
+		}
+		be.pipeline_end(G);
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	else
+	for (;;)
+	{
+		const auto t0 = now();
+		// every window says what it wants next (its own point, value or value + Jacobian);
+		// finished windows drop out of the launch
+		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
+			for (size_t w = b; w < e; ++w)
+			{
+				const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
+				wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+				std::memset(&modes[w * P], wmode[w], static_cast<size_t>(P));
+			}
+		});
+		bool any = false, anyJac = false, uniform = true;
+		for (int w = 0; w < Wn; ++w)
+		{
+			any = any || wmode[w] != 0;
+			anyJac = anyJac || wmode[w] == 2;
+			uniform = uniform && wmode[w] == wmode[0];
+		}
+		if (!any)
+		{
+			break;
+		}
+		// all windows in the same phase (always so for a single window): no mode table needed
+		const auto t1 = now();
+		int rc = be.eval(flows.data(), r.data(), anyJac ? J.data() : nullptr, uniform ? nullptr : modes.data());
+		if (rc)
+		{
+			return rc;
+		}
+		const auto t2 = now();
+		pool.parallel_for(static_cast<size_t>(Wn), 2, [&](size_t b, size_t e) {
+			for (size_t w = b; w < e; ++w)
+			{
+				if (wmode[w] != 0)
+				{
+					lm[w].supply(&r[w * P], wmode[w] == 2 ? &J[w * P * 2] : nullptr);
+				}
+			}
+		});
+		const auto t3 = now();
+		tReq += ms(t0, t1);
+		tEval += ms(t1, t2);
+		tSup += ms(t2, t3);
+		++rounds;
+	}
+	if (trace)
+	{
+		std::fprintf(stderr, "[ebo] lock-step solve: %d windows, %d rounds: request %.2f ms, evaluation (staging + kernels + sync; pipelined: waiting only) %.2f ms, supply (LM steps) %.2f ms\n",
+					 Wn, rounds, tReq, tEval, tSup);
+	}
+	return 0;
+}
+
+// One 2-parameter HostLm per active patch (lms[k] owns flow slot slot[k] of nf), all advanced in lock step.
+template <class Backend>
+int lockstep_independent(Backend& be, std::vector<HostLm>& lms, const std::vector<size_t>& slot, size_t nf,
+						 std::vector<double>& flows)
+{
+	flows.assign(nf * 2, 0.0);
+	std::vector<double> r(nf), J(nf * 2);
+	std::vector<unsigned char> modes(nf, 0);
+	HostPool pool(lms.size(), 256);
+	for (;;)
+	{
+		// every patch says what it wants next; finished patches drop out of the launch
+		pool.parallel_for(lms.size(), 256, [&](size_t b, size_t e) {
+			for (size_t k = b; k < e; ++k)
+			{
+				const HostLm::Request q = lms[k].request(&flows[2 * slot[k]]);
+				modes[slot[k]] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+			}
+		});
+		bool any = false, anyJac = false;
+		for (size_t k = 0; k < lms.size(); ++k)
+		{
+			any = any || modes[slot[k]] != 0;
+			anyJac = anyJac || modes[slot[k]] == 2;
+		}
+		if (!any)
+		{
+			break;
+		}
+		const int rc = be.eval(flows.data(), r.data(), anyJac ? J.data() : nullptr, modes.data());
+		if (rc)
+		{
+			return rc;
+		}
+		pool.parallel_for(lms.size(), 256, [&](size_t b, size_t e) {
+			for (size_t k = b; k < e; ++k)
+			{
+				if (modes[slot[k]] != 0)
+				{
+					lms[k].supply(&r[slot[k]], modes[slot[k]] == 2 ? &J[2 * slot[k]] : nullptr);
+				}
+			}
+		});
+	}
+	return 0;
+}
+}  // namespace ebo

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <deque>
 #include <vector>
@@ -52,6 +53,7 @@ class Patch
 		initPoint_ = toCorner();
 		counter_ = 0;
 		integratedNabla_ = Mat64(static_cast<int>(patch_.height), static_cast<int>(patch_.width));
+		predictedNabla_ = Mat64(static_cast<int>(patch_.height), static_cast<int>(patch_.width));  // patch.cpp:28: zeros
 		motionCompensatedIntegratedNabla_ = Mat64(static_cast<int>(patch_.height), static_cast<int>(patch_.width));
 		timeWithoutUpdate_ = common::timestamp_t(static_cast<int64_t>(1e7));
 		initTime_ = currentTimestamp_;
@@ -91,6 +93,34 @@ class Patch
 		resetBatch();
 	}
 
+	// patch.cpp:132-154, called per patch at feature_detector.cpp:508,615: the predicted gradient patch
+	//     predictedNabla_ = -warpedGradX(patch_) cos(flowDir_) - warpedGradY(patch_) sin(flowDir_),
+	// the gradient images warped by cv::warpAffine(..., warp_.matrix2x3(), cv::WARP_INVERSE_MAP).  The
+	// reference's Patch holds gradX_ / gradY_ (setGrad); here they live on the device in `ctx`
+	// (ebo_optimizer_set_grad, what tracker::Optimizer::setGrad / TrackedPatches::setGradients install)
+	// and the warp runs there (ebo_patch_warp_image).  A rect that touches the image border leaves
+	// predictedNabla_ as it was (:145-150) -- with the reference's own test set-up (patch_test.cpp:62-108:
+	// an 11x11 image and a patch of extent 5 at its centre) that is every call, and the image stays 0.
+	// false: the device call failed (ebo_last_error(ctx)).
+	bool warpImage(ebo_ctx* ctx)
+	{
+		const double rect[4] = {patch_.x, patch_.y, patch_.width, patch_.height};
+		const size_t off = 0;
+		Mat64 out(static_cast<int>(std::nearbyint(patch_.height)), static_cast<int>(std::nearbyint(patch_.width)));
+		int32_t updated = 0;
+		if (ebo_patch_warp_image(ctx, 1, rect, warp_.data(), &flowDir_, &off, out.ptr(), &updated) != EBO_OK)
+		{
+			return false;
+		}
+		if (updated)
+		{
+			predictedNabla_ = out;
+		}
+		return true;
+	}
+	Mat64 const& getPredictedNabla() const { return predictedNabla_; }
+	void setPredictedNabla(const Mat64& m) { predictedNabla_ = m; }
+
 	void resetBatch() { counter_ = 0; }
 	void addTrajectoryPosition() { trajectory_.push_back({toCorner(), currentTimestamp_}); }
 	void addFinalCost(double finalCost) { finalCosts_.emplace_back(finalCost); }
@@ -115,6 +145,7 @@ class Patch
 	TrackId getTrackId() const { return trackId_; }
 	const common::Pose2d& getWarp() const { return warp_; }
 	float getFlow() const { return static_cast<float>(flowDir_); }  // float, as the reference (patch.h:56)
+	double getFlowDir() const { return flowDir_; }                 // the member itself (what warpImage reads)
 	std::vector<common::Sample<common::Point2d>> const& getTrajectory() const { return trajectory_; }
 	size_t getNumOfEvents() const { return numOfEvents_; }
 	common::timestamp_t getCurrentTimestamp() const { return currentTimestamp_; }
@@ -166,6 +197,7 @@ class Patch
 	size_t maxNumOfEvents_ = 300;
 	size_t counter_ = 0;
 	Mat64 integratedNabla_;
+	Mat64 predictedNabla_;
 	Mat64 motionCompensatedIntegratedNabla_;
 	double flowDir_ = 0.0;
 	common::Pose2d warp_;

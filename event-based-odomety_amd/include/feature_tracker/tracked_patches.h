@@ -22,8 +22,12 @@
 // neighbour through OpenCV's 10-bit fixed-point map, and the L1 norm over the rect) on the device
 // (ebo_estimate_num_events) from the gradient images given to setGradients -- gradX_ / gradY_ of the
 // latest frame in the reference (:516-517).  setNumOfEventsEstimator overrides it; without gradients
-// and without an estimator a patch keeps its event count.  Patch::warpImage (a visualisation, :615)
-// is not built.
+// and without an estimator a patch keeps its event count.  Patch::warpImage (:615, after every
+// optimisation: the predicted gradient patch, a visualisation) runs on the device too
+// (ebo_patch_warp_image, one launch for the patches of a round that share an optimiser) against the
+// gradient images of the patch's OWN frame -- the reference's Patch keeps the cv::Mat headers it was
+// given when it was extracted (setGrad, :508 region), which are the images its frame's Optimizer holds;
+// setWarpImages(false) skips it.
 #pragma once
 
 #include <algorithm>
@@ -149,6 +153,49 @@ class TrackedPatches
 		}
 	}
 
+	// Patch::warpImage (patch.cpp:132-154) for patches that share an optimiser, i.e. a frame's gradient
+	// images: one launch.  A rect that touches the image border keeps its old predictedNabla_ (:145-150).
+	void setWarpImages(bool on) { warpImages_ = on; }
+	void warpImages(const std::vector<Patch*>& patches, ebo_ctx* gradCtx)
+	{
+		if (!warpImages_ || patches.empty())
+		{
+			return;
+		}
+		const size_t n = patches.size();
+		std::vector<double> rects(4 * n), poses(4 * n), flows(n);
+		std::vector<size_t> off(n, 0);
+		std::vector<int32_t> updated(n, 0);
+		size_t total = 0;
+		for (size_t i = 0; i < n; ++i)
+		{
+			const Rect2d& r = patches[i]->getPatch();
+			rects[4 * i + 0] = r.x;
+			rects[4 * i + 1] = r.y;
+			rects[4 * i + 2] = r.width;
+			rects[4 * i + 3] = r.height;
+			const double* w = patches[i]->getWarp().data();
+			std::copy(w, w + 4, &poses[4 * i]);
+			flows[i] = patches[i]->getFlowDir();  // the double member, as patch.cpp:152
+			off[i] = total;
+			total += static_cast<size_t>(std::nearbyint(r.height)) * static_cast<size_t>(std::nearbyint(r.width));
+		}
+		std::vector<double> out(total > 0 ? total : 1, 0.0);
+		check(ebo_patch_warp_image(gradCtx, static_cast<int>(n), rects.data(), poses.data(), flows.data(), off.data(), out.data(),
+								   updated.data()));
+		for (size_t i = 0; i < n; ++i)
+		{
+			if (updated[i])
+			{
+				const Rect2d& r = patches[i]->getPatch();
+				Mat64 m(static_cast<int>(std::nearbyint(r.height)), static_cast<int>(std::nearbyint(r.width)));
+				std::copy(out.begin() + static_cast<std::ptrdiff_t>(off[i]),
+						  out.begin() + static_cast<std::ptrdiff_t>(off[i] + static_cast<size_t>(m.rows) * m.cols), m.ptr());
+				patches[i]->setPredictedNabla(m);
+			}
+		}
+	}
+
 	// feature_detector.cpp:585-619, one event
 	void updatePatches(const common::EventSample& event)
 	{
@@ -162,8 +209,10 @@ class TrackedPatches
 				}
 				if (patch.isReady() && patch.isInit())
 				{
-					optimizerOf(patch).optimize(patch);
+					Optimizer& opt = optimizerOf(patch);
+					opt.optimize(patch);
 					updateNumOfEvents(patch);
+					warpImages(std::vector<Patch*>(1, &patch), opt.handle());  // :615
 				}
 			}
 		}
@@ -273,6 +322,7 @@ class TrackedPatches
 				}
 				it->second->optimize(group.second);
 				updateNumOfEvents(group.second);  // also after a patch was lost in optimize, as :613-614
+				warpImages(group.second, it->second->handle());  // :615
 			}
 			live.clear();
 			for (int i : still)
@@ -313,6 +363,7 @@ class TrackedPatches
 	std::map<int64_t, std::shared_ptr<Optimizer>> optimizers_;
 	std::function<size_t(const Patch&)> estimator_;
 	bool haveGradients_ = false;
+	bool warpImages_ = true;
 	int rounds_ = 0;
 };
 

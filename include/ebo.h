@@ -309,6 +309,18 @@ int ebo_optimizer_solve(ebo_ctx* ctx, int n, const double* rects, const double* 
 int ebo_estimate_num_events(ebo_ctx* ctx, int n, const double* rects, const double* poses, const double* flow_dirs,
 							uint64_t* out);
 
+/* tracker::Patch::warpImage (patch.cpp:132-154; called at feature_detector.cpp:508,615) for n tracked
+ * patches in one launch: predictedNabla_ = -gradX'(patch_) cos(flowDir_) - gradY'(patch_) sin(flowDir_) with
+ * gradX' / gradY' = the gradient images of ebo_optimizer_set_grad warped by cv::warpAffine(...,
+ * warp_.matrix2x3(), cv::WARP_INVERSE_MAP) (INTER_NEAREST through OpenCV's 10-bit fixed-point map,
+ * BORDER_CONSTANT 0, as ebo_estimate_num_events) and flowDir_ the patch's double member.  rects [n][4] =
+ * cv::Rect2d, poses [n][4] = Sophus::SE2d::data(), flow_dirs [n]; patch i's [cvRound(h)][cvRound(w)] image
+ * goes to predicted + nabla_offsets[i].  updated[i] = 0 and nothing is written for a patch whose rect
+ * touches the image border (the reference returns early at :145-150 and keeps the old predictedNabla_).
+ * EBO_ERR_STATE without ebo_optimizer_set_grad. */
+int ebo_patch_warp_image(ebo_ctx* ctx, int n, const double* rects, const double* poses, const double* flow_dirs,
+						 const size_t* nabla_offsets, double* predicted, int32_t* updated);
+
 /* Event -> tracked-patch routing: what FeatureDetector::updatePatches does per event,
  * `if (patch.isInPatch(event.value.point)) patch.addEvent(event)` (feature_detector.cpp:585-596;
  * cv::Rect2d::contains on the integer point: x <= px < x + w, y <= py < y + h in double), for a

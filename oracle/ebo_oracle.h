@@ -234,6 +234,8 @@ int orc_patch_update_rect(const double* warp, double init_x, double init_y, doub
  * in the image: restated from its published algorithm (imgproc/imgwarp.cpp, cv::warpAffine /
  * WarpAffineInvoker), PARITY UNPINNED; exact by construction for identity and integer-translation
  * warps.  grad [img_h][img_w][2] = (gradX, gradY); warp [4] = Sophus::SE2d::data(). */
+int orc_patch_warp_image(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+						 const double* warp, double flow_dir, double* out, int* updated);
 int orc_estimate_num_events(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
 							const double* warp, double flow_dir, uint64_t* out);
 /* Patch::getNormalizedIntegratedNabla (patch.cpp:156-159). */

@@ -973,6 +973,52 @@ int orc_estimate_num_events(const double* grad, int img_w, int img_h, double rx,
 	return 0;
 }
 
+// Patch::warpImage (patch.cpp:132-154): the two gradient images through cv::warpAffine(..., warp_.matrix2x3(),
+// cv::WARP_INVERSE_MAP) -- the same nearest-neighbour fixed-point map as above --, then, unless the patch
+// rect touches the image border (:145-150: `patch_.x < 0 || patch_.y < 0 || patch_.x + patch_.width >= cols
+// || patch_.y + patch_.height >= rows` -> return, predictedNabla_ keeps its value),
+//     predictedNabla_ = -warpedGradX(patch_) * cos(flowDir_) - warpedGradY(patch_) * sin(flowDir_)
+// over the rect (cv::Rect2d -> cv::Rect by cvRound).  flowDir_ is the double member here (not the float
+// getFlow() returns).  The MatExpr folds the signs into the scales: one gx * (-cos) + gy * (-sin) per pixel
+// (cv::addWeighted).  out: [h][w] row-major, h = cvRound(rh), w = cvRound(rw); *updated = 0 on the early
+// return (out untouched).
+int orc_patch_warp_image(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+						 const double* warp, double flow_dir, double* out, int* updated)
+{
+	if (!grad || !warp || !out || !updated || img_w <= 0 || img_h <= 0)
+	{
+		return -1;
+	}
+	*updated = 0;
+	if (rx < 0 || ry < 0 || rx + rw >= img_w || ry + rh >= img_h)
+	{
+		return 0;
+	}
+	const double M[6] = {warp[0], -warp[1], warp[2], warp[1], warp[0], warp[3]};
+	const int x0 = static_cast<int>(std::lrint(rx)), y0 = static_cast<int>(std::lrint(ry));
+	const int w = static_cast<int>(std::lrint(rw)), h = static_cast<int>(std::lrint(rh));
+	const double a = -std::cos(flow_dir), b = -std::sin(flow_dir);
+	for (int y = y0; y < y0 + h; ++y)
+	{
+		const int X0 = static_cast<int>(std::lrint((M[1] * y + M[2]) * 1024.0)) + 512;
+		const int Y0 = static_cast<int>(std::lrint((M[4] * y + M[5]) * 1024.0)) + 512;
+		for (int x = x0; x < x0 + w; ++x)
+		{
+			const int X = (X0 + static_cast<int>(std::lrint(M[0] * x * 1024.0))) >> 10;
+			const int Y = (Y0 + static_cast<int>(std::lrint(M[3] * x * 1024.0))) >> 10;
+			double gx = 0.0, gy = 0.0;
+			if (x >= 0 && x < img_w && y >= 0 && y < img_h && X >= 0 && X < img_w && Y >= 0 && Y < img_h)
+			{
+				gx = grad[2 * (static_cast<size_t>(Y) * img_w + X)];
+				gy = grad[2 * (static_cast<size_t>(Y) * img_w + X) + 1];
+			}
+			out[static_cast<size_t>(y - y0) * w + (x - x0)] = gx * a + gy * b;
+		}
+	}
+	*updated = 1;
+	return 0;
+}
+
 int orc_patch_update_rect(const double* warp, double init_x, double init_y, double rw, double rh, double* rect)
 {
 	if (!warp || !rect)

@@ -735,6 +735,61 @@ int main()
 		EXPECT_TRUE(seq.getPatches()[5].isLost() && seq.getPatches()[5].getFinalCosts().size() == 1);  // centre within 5 px of the border
 	}
 
+	// ---- Patch::warpImage: the reference's warpImageTest (patch_test.cpp:62-108) through the facade ----
+	for (int n : {11, 15})
+	{
+		// cv::line(gradX, {c, 0}, {c, n-1}, 1); cv::line(gradY, {0, c}, {n-1, c}, 1)
+		const int c0 = n / 2;
+		tracker::Mat64 gradX(n, n), gradY(n, n);
+		for (int k = 0; k < n; ++k)
+		{
+			gradX.at<double>(k, c0) = 1.0;
+			gradY.at<double>(c0, k) = 1.0;
+		}
+		tracker::Patch patch(tracker::Corner(c0, c0), 5, common::timestamp_t(0));
+		const float angle = static_cast<float>(M_PI / 4);
+		patch.setFlowDir(angle);
+		patch.setWarp(common::Pose2d(M_PI / 4, common::Point2d(0.0, 0.0)));  // Sophus::SE2d::rot(M_PI / 4)
+		tracker::OptimizerParams wp;
+		tracker::Optimizer holder(wp, tracker::Size(n, n));  // the frame's gradient images live in its context
+		holder.setGrad(gradX, gradY);                        // patch.setGrad(gradX, gradY)
+		EXPECT_TRUE(patch.warpImage(holder.handle()));
+		const tracker::Mat64& image = patch.getPredictedNabla();
+		EXPECT_TRUE(image.rows == 11 && image.cols == 11);
+		bool anyNegative = false;
+		for (int i = 1; i < 10; ++i)
+		{
+			for (int j = 1; j < 10; ++j)
+			{
+				if (i == j || i == 10 - j)
+				{
+					EXPECT_TRUE(image.at<double>(i, j) <= 0);  // EXPECT_LE(image.at<double>(i, j), 0)
+				}
+				anyNegative = anyNegative || image.at<double>(i, j) < 0;
+			}
+		}
+		// n = 11 is the reference's set-up: the rect touches the border, warpImage returns early (patch.cpp:145-150)
+		// and the image is still Patch::init's zeros; n = 15 clears the border and the warp runs
+		EXPECT_TRUE(anyNegative == (n == 15));
+		// against the oracle's restatement, pixel by pixel
+		std::vector<double> grad(static_cast<size_t>(n) * n * 2);
+		for (int k = 0; k < n * n; ++k)
+		{
+			grad[2 * k] = gradX.ptr()[k];
+			grad[2 * k + 1] = gradY.ptr()[k];
+		}
+		std::vector<double> want(121, 0.0);
+		int updated = -1;
+		const tracker::Rect2d& r = patch.getPatch();
+		EXPECT_TRUE(orc_patch_warp_image(grad.data(), n, n, r.x, r.y, r.width, r.height, patch.getWarp().data(), patch.getFlowDir(),
+										 want.data(), &updated) == 0);
+		EXPECT_TRUE(updated == (n == 15 ? 1 : 0));
+		for (int k = 0; k < 121; ++k)
+		{
+			EXPECT_TRUE(std::fabs(want[k] - image.ptr()[k]) <= 1e-15);
+		}
+	}
+
 	std::printf(g_fail ? "facade_test: %d FAILED\n" : "facade_test: all passed\n", g_fail);
 	return g_fail ? 1 : 0;
 }

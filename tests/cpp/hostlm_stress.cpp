@@ -1,0 +1,284 @@
+// hostlm_stress.cpp — the product's HOST concurrency on the CPU, for the sanitizers.
+//
+// csrc/host_pool.h (the spin-then-park thread pool of the lock-step solves) and csrc/lockstep.h (the
+// lock-step drivers, incl. the pipelined one with several groups of windows in flight) are header-only and
+// free of HIP; libebo_hip.so instantiates the drivers with the device as the backend.  This program
+// instantiates the SAME code with a CPU objective that is evaluated on ANOTHER THREAD (as the device is
+// asynchronous to the host), and is built three ways by tests/cpp/Makefile -- plain, -fsanitize=thread,
+// -fsanitize=address,undefined -- and run by tests/test_host_sanitizers.py with 1..16 host threads
+// (EBO_HOST_THREADS).  Test infrastructure; nothing here is measured or shipped.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../event-based-odomety_amd/csrc/lockstep.h"
+
+static int failures = 0;
+#define EXPECT_TRUE(c)                                                    \
+	do                                                                    \
+	{                                                                     \
+		if (!(c))                                                         \
+		{                                                                 \
+			std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c);    \
+			++failures;                                                   \
+		}                                                                 \
+	} while (0)
+
+// ---- 1. the pool alone: many short rounds, pools created and destroyed per "call" ----------------
+static void poolStress(int calls, int rounds)
+{
+	for (int call = 0; call < calls; ++call)
+	{
+		const size_t problems = 1 + static_cast<size_t>((call * 37) % 400);
+		ebo::HostPool pool(problems, 1 + call % 3);
+		std::vector<long> cell(problems, 0);
+		long expect = 0;
+		for (int round = 0; round < rounds; ++round)
+		{
+			const size_t n = 1 + static_cast<size_t>((round * 131 + call) % problems);
+			pool.parallel_for(n, 1 + round % 4, [&](size_t b, size_t e) {
+				for (size_t k = b; k < e; ++k)
+				{
+					cell[k] += static_cast<long>(k) + round;  // every index belongs to exactly one chunk
+				}
+			});
+			for (size_t k = 0; k < n; ++k)
+			{
+				expect += static_cast<long>(k) + round;
+			}
+		}
+		EXPECT_TRUE(std::accumulate(cell.begin(), cell.end(), 0L) == expect);
+	}
+}
+
+// ---- 2. a CPU backend: a smooth 2-parameter objective per flow slot, evaluated asynchronously ------
+struct CpuBackend
+{
+	CpuBackend(size_t slots, bool pipeline, int groups) : n(slots), pipe(pipeline), G(groups), t0(slots), t1(slots), amp(slots)
+	{
+		for (size_t i = 0; i < slots; ++i)
+		{
+			t0[i] = 0.4 * std::sin(0.37 * static_cast<double>(i) + 0.2);
+			t1[i] = 0.3 * std::cos(0.91 * static_cast<double>(i));
+			amp[i] = 40.0 + 10.0 * std::sin(1.3 * static_cast<double>(i));
+		}
+	}
+	void one(size_t i, const double* x, double& r, double* J) const
+	{
+		const double d0 = x[0] - t0[i], d1 = x[1] - t1[i];
+		const double e = amp[i] * std::exp(-0.5 * (d0 * d0 + d1 * d1));
+		r = 1000.0 - e;  // the shape of the contrast residual: maxPossibleResidual - contrast
+		if (J)
+		{
+			J[0] = e * d0;
+			J[1] = e * d1;
+		}
+	}
+	int eval(const double* flows, double* r, double* J, const unsigned char* modes)
+	{
+		for (size_t i = 0; i < n; ++i)
+		{
+			if (modes && modes[i] == 0)
+			{
+				continue;
+			}
+			double jj[2];
+			const bool wantJ = J && (!modes || modes[i] == 2);
+			one(i, flows + 2 * i, r[i], wantJ ? jj : nullptr);
+			if (wantJ)
+			{
+				J[2 * i] = jj[0];
+				J[2 * i + 1] = jj[1];
+			}
+		}
+		++evals;
+		return 0;
+	}
+	bool pipelined(int windows, size_t) const { return pipe && windows >= 4; }
+	int groups() const { return G; }
+	int pipeline_begin(size_t slots, int groupsNow)
+	{
+		stage.assign(static_cast<size_t>(groupsNow), std::vector<double>(3 * slots, 0.0));
+		stageFlows.assign(static_cast<size_t>(groupsNow), std::vector<double>(2 * slots, 0.0));
+		stageModes.assign(static_cast<size_t>(groupsNow), std::vector<unsigned char>(slots, 0));
+		workers.resize(static_cast<size_t>(groupsNow));
+		return 0;
+	}
+	void pipeline_end(int)
+	{
+		for (auto& t : workers)
+		{
+			if (t.joinable())
+			{
+				t.join();
+			}
+		}
+	}
+	// like the device: the inputs are copied before the call returns, the work happens elsewhere
+	int eval_begin(const double* flows, const unsigned char* modes, int g, size_t s0, size_t s1, bool)
+	{
+		std::memcpy(&stageFlows[g][2 * s0], flows + 2 * s0, (s1 - s0) * 2 * sizeof(double));
+		std::memcpy(stageModes[g].data(), modes, n);
+		workers[g] = std::thread([this, g, s0, s1] {
+			for (size_t i = s0; i < s1; ++i)
+			{
+				if (stageModes[g][i] == 0)
+				{
+					continue;
+				}
+				one(i, &stageFlows[g][2 * i], stage[g][3 * i], stageModes[g][i] == 2 ? &stage[g][3 * i + 1] : nullptr);
+			}
+		});
+		++evals;
+		return 0;
+	}
+	int eval_finish(const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, double* r, double* J)
+	{
+		workers[g].join();
+		for (size_t i = s0; i < s1; ++i)
+		{
+			if (modes[i] == 0)
+			{
+				continue;
+			}
+			r[i] = stage[g][3 * i];
+			if (wantJac && modes[i] == 2)
+			{
+				J[2 * i] = stage[g][3 * i + 1];
+				J[2 * i + 1] = stage[g][3 * i + 2];
+			}
+		}
+		return 0;
+	}
+	size_t n;
+	bool pipe;
+	int G;
+	int evals = 0;
+	std::vector<double> t0, t1, amp;
+	std::vector<std::vector<double>> stage, stageFlows;
+	std::vector<std::vector<unsigned char>> stageModes;
+	std::vector<std::thread> workers;
+};
+
+static std::vector<double> solveGlobal(int Wn, int npx, int npy, bool pipeline, int groups, int* iterations)
+{
+	const int P = npx * npy;
+	ebo_solver_opts o;
+	std::memset(&o, 0, sizeof(o));
+	o.max_num_iterations = 50;
+	o.use_nonmonotonic = 1;
+	o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = 1e-12;
+	o.initial_radius = 1e4;
+	o.max_radius = 1e16;
+	o.min_radius = 1e-32;
+	o.min_relative_decrease = 1e-3;
+	o.min_lm_diagonal = 1e-6;
+	o.max_lm_diagonal = 1e32;
+	o.max_consecutive_nonmonotonic = 5;
+	o.max_consecutive_invalid = 5;
+	o.jacobi_scaling = 1;
+	o.mode = EBO_SOLVE_GLOBAL;
+	std::vector<ebo::HostLm> lm;
+	lm.reserve(static_cast<size_t>(Wn));
+	for (int w = 0; w < Wn; ++w)
+	{
+		std::vector<uint8_t> active(static_cast<size_t>(P), 1);
+		active[static_cast<size_t>((w * 5) % P)] = 0;  // an inactive patch per window, as real windows have
+		lm.emplace_back(npx, npy, active, 1e3, 10.0, o);
+	}
+	CpuBackend be(static_cast<size_t>(Wn) * P, pipeline, groups);
+	std::vector<double> flows;
+	EXPECT_TRUE(ebo::lockstep_global(be, Wn, P, lm, flows, false) == 0);
+	std::vector<double> out(static_cast<size_t>(Wn) * P * 2, 0.0);
+	int it = 0;
+	for (int w = 0; w < Wn; ++w)
+	{
+		lm[static_cast<size_t>(w)].result(&out[static_cast<size_t>(w) * P * 2]);
+		it = std::max(it, lm[static_cast<size_t>(w)].stats().iterations);
+	}
+	*iterations = it;
+	return out;
+}
+
+static std::vector<double> solveIndependent(size_t nf)
+{
+	ebo_solver_opts o;
+	std::memset(&o, 0, sizeof(o));
+	o.max_num_iterations = 30;
+	o.use_nonmonotonic = 1;
+	o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = 1e-12;
+	o.initial_radius = 1e4;
+	o.max_radius = 1e16;
+	o.min_radius = 1e-32;
+	o.min_relative_decrease = 1e-3;
+	o.min_lm_diagonal = 1e-6;
+	o.max_lm_diagonal = 1e32;
+	o.max_consecutive_nonmonotonic = 5;
+	o.max_consecutive_invalid = 5;
+	o.jacobi_scaling = 1;
+	o.mode = EBO_SOLVE_INDEPENDENT;
+	std::vector<ebo::HostLm> lms;
+	std::vector<size_t> slot;
+	const std::vector<uint8_t> one(1, 1);
+	for (size_t i = 0; i < nf; ++i)
+	{
+		if (i % 7 != 3)  // some slots have no problem (inactive patches)
+		{
+			lms.emplace_back(1, 1, one, 0.0, 10.0, o);
+			slot.push_back(i);
+		}
+	}
+	CpuBackend be(nf, false, 2);
+	std::vector<double> flows;
+	EXPECT_TRUE(ebo::lockstep_independent(be, lms, slot, nf, flows) == 0);
+	std::vector<double> out(nf * 2, 0.0);
+	for (size_t k = 0; k < lms.size(); ++k)
+	{
+		lms[k].result(&out[2 * slot[k]]);
+	}
+	return out;
+}
+
+int main(int argc, char** argv)
+{
+	const int scale = argc > 1 ? std::atoi(argv[1]) : 1;  // the sanitizer builds run a smaller campaign
+	poolStress(40 * scale, 200);
+	int itPlain = 0, itPipe = 0, itPipe4 = 0;
+	const std::vector<double> plain = solveGlobal(24, 6, 4, false, 2, &itPlain);
+	const std::vector<double> piped = solveGlobal(24, 6, 4, true, 2, &itPipe);
+	const std::vector<double> piped4 = solveGlobal(24, 6, 4, true, 4, &itPipe4);
+	EXPECT_TRUE(itPlain > 3 && itPlain == itPipe && itPlain == itPipe4);
+	// per window the same requests in the same order: the pipelined solves equal the plain one bit for bit
+	EXPECT_TRUE(std::memcmp(plain.data(), piped.data(), plain.size() * sizeof(double)) == 0);
+	EXPECT_TRUE(std::memcmp(plain.data(), piped4.data(), plain.size() * sizeof(double)) == 0);
+	double moved = 0.0;
+	for (double v : plain)
+	{
+		moved = std::fmax(moved, std::fabs(v));
+	}
+	EXPECT_TRUE(moved > 0.05 && moved < 2.0);  // the flows went to the objectives' minima, coupled by the TV terms
+	const std::vector<double> a = solveIndependent(600), b = solveIndependent(600);
+	EXPECT_TRUE(std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) == 0);
+	EXPECT_TRUE(a[2 * 3] == 0.0 && a[2 * 3 + 1] == 0.0);  // a slot without a problem keeps the zero flow
+	{
+		// slot 0 ended at a lower residual than it started from (the solver returns its lowest-cost point)
+		CpuBackend probe(600, false, 2);
+		double r0, r1;
+		const double zero[2] = {0.0, 0.0};
+		probe.one(0, zero, r0, nullptr);
+		probe.one(0, &a[0], r1, nullptr);
+		EXPECT_TRUE(r1 < r0 && std::isfinite(a[0]) && std::isfinite(a[1]));
+	}
+	if (failures == 0)
+	{
+		std::printf("hostlm_stress: all passed (%d LM iterations, pool + plain / 2-group / 4-group pipelined lock step, %s host threads)\n",
+					itPlain, std::getenv("EBO_HOST_THREADS") ? std::getenv("EBO_HOST_THREADS") : "default");
+		return 0;
+	}
+	std::printf("hostlm_stress: %d failures\n", failures);
+	return 1;
+}

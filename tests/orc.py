@@ -391,6 +391,20 @@ def optimizer_solve(grad, rect, nabla, pose, flow_dir, huber=0.3, opts=None):
     return p, fd.value, s
 
 
+def patch_warp_image(grad, rect, pose, flow_dir):
+    """Patch::warpImage (patch.cpp:132-154) -> (predictedNabla [h][w] or None on the border return)"""
+    grad = np.ascontiguousarray(grad, dtype=np.float64)
+    h, w = grad.shape[:2]
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    ph, pw = int(np.rint(rect[3])), int(np.rint(rect[2]))
+    out = np.zeros((ph, pw))
+    upd = C.c_int()
+    rc = lib().orc_patch_warp_image(_dp(grad), w, h, C.c_double(rect[0]), C.c_double(rect[1]), C.c_double(rect[2]),
+                                    C.c_double(rect[3]), _dp(pose), C.c_double(flow_dir), _dp(out), C.byref(upd))
+    assert rc == 0
+    return out if upd.value else None
+
+
 def estimate_num_events(grad, rect, pose, flow_dir):
     """The event-count estimate of FeatureDetector::updateNumOfEvents (feature_detector.cpp:689-707)."""
     grad = np.ascontiguousarray(grad, dtype=np.float64)

@@ -1,0 +1,46 @@
+"""CPU: the product's host concurrency under the sanitizers (SURVEY section 5 puts sanitizers on the CPU build).
+
+csrc/host_pool.h (the spin-then-park thread pool that lives for one solve call) and csrc/lockstep.h (the
+lock-step drivers of EBO_SOLVE_GLOBAL / the lock-step EBO_SOLVE_INDEPENDENT, incl. the pipelined form with
+2-4 groups of windows in flight) are the code libebo_hip.so ships; they are free of HIP, and
+tests/cpp/hostlm_stress.cpp instantiates them with a CPU objective evaluated on another thread (the device is
+asynchronous to the host in the same way).  Built with -fsanitize=thread and with
+-fsanitize=address,undefined and run with 1..16 host threads, with and without the spin phase: no report,
+and the pipelined solves equal the plain one bit for bit."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPP = os.path.join(HERE, "cpp")
+
+
+def _run(binary, threads, spin_us=None, scale="1"):
+    env = dict(os.environ, EBO_HOST_THREADS=str(threads))
+    if spin_us is not None:
+        env["EBO_HOST_SPIN_US"] = str(spin_us)
+    env.setdefault("TSAN_OPTIONS", "halt_on_error=1")
+    out = subprocess.run([os.path.join(CPP, binary), scale], env=env, capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert "all passed" in out.stdout
+    for bad in ("ThreadSanitizer", "AddressSanitizer", "runtime error", "LeakSanitizer"):
+        assert bad not in text, text[-3000:]
+
+
+def test_host_stress_plain_build():
+    subprocess.check_call(["make", "-s", "-C", CPP, "hostlm_stress"])
+    _run("hostlm_stress", 8, scale="2")
+
+
+@pytest.mark.parametrize("threads,spin_us", [(1, None), (2, None), (5, None), (16, None), (6, 0), (16, 2000)])
+def test_host_pool_and_lock_step_drivers_under_thread_sanitizer(threads, spin_us):
+    subprocess.check_call(["make", "-s", "-C", CPP, "hostlm_stress_tsan"])
+    _run("hostlm_stress_tsan", threads, spin_us)
+
+
+@pytest.mark.parametrize("threads", [1, 4, 16])
+def test_host_pool_and_lock_step_drivers_under_address_and_ub_sanitizers(threads):
+    subprocess.check_call(["make", "-s", "-C", CPP, "hostlm_stress_asan"])
+    _run("hostlm_stress_asan", threads)
