@@ -250,13 +250,18 @@ def write_tracks_txt(path, pts):
         raise EboError(rc, "cannot write %s" % path)
 
 
-def read_tracks_txt(path, cap=1 << 20):
-    out = np.zeros(cap, dtype=TRACK_DTYPE)
-    n = C.c_size_t()
-    rc = lib().ebo_read_tracks_txt(str(path).encode(), _vp(out), C.c_size_t(cap), C.byref(n))
-    if rc:
-        raise EboError(rc, "cannot parse %s (parsed %d records before the error)" % (path, n.value))
-    return out[: n.value].copy()
+def read_tracks_txt(path, cap=1 << 16):
+    """trajectory.txt -> track records; the buffer grows to what the file holds (never a truncated list)."""
+    while True:
+        out = np.zeros(cap, dtype=TRACK_DTYPE)
+        n = C.c_size_t()
+        rc = lib().ebo_read_tracks_txt(str(path).encode(), _vp(out), C.c_size_t(cap), C.byref(n))
+        if rc == ERR_ARG and n.value > cap:
+            cap = n.value
+            continue
+        if rc:
+            raise EboError(rc, "cannot parse %s (parsed %d records before the error)" % (path, n.value))
+        return out[: n.value].copy()
 
 
 def pack_events8(ev, t_base, out=None):

@@ -357,10 +357,21 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	L.ec.cs_stride = L.cap_px;
 	{
 		const size_t need = static_cast<size_t>(L.n_units) * L.cap_px * 2 * sizeof(double);
-		const size_t limit = env_size("EBO_EDGE_CS_MB", 4096) << 20;
+		// The table is an optimisation nobody asked for by name, so it must not surprise: at most
+		// EBO_EDGE_CS_MB (default 4096) AND at most a quarter of the memory that is free right now
+		// (several contexts share a GPU: one per FeatureDetector / Optimizer / TrackedPatches of the
+		// facade, the ranks of a rehearsal); a failed allocation is not an error (the reverse pass
+		// re-derives what the table would have held); and a context that kept a large table for one
+		// big batch gives it back when the batches that follow need less than a quarter of it.
+		size_t limit = env_size("EBO_EDGE_CS_MB", 4096) << 20;
+		size_t freeB = 0, totalB = 0;
+		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
+		{
+			limit = std::min(limit, (freeB + c->edge_cs_cap) / 4);
+		}
 		if (L.want_jac && L.flow_sets == 1 && need <= limit && need > 0)
 		{
-			if (need > c->edge_cs_cap)
+			if (need > c->edge_cs_cap || need < c->edge_cs_cap / 4)
 			{
 				if (c->d_edge_cs)
 				{
@@ -369,12 +380,15 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 					c->d_edge_cs = nullptr;
 					c->edge_cs_cap = 0;
 				}
-				rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_edge_cs), need), "hipMalloc edge directions");
-				if (rc)
+				if (hipMalloc(reinterpret_cast<void**>(&c->d_edge_cs), need) == hipSuccess)
 				{
-					return rc;
+					c->edge_cs_cap = need;
 				}
-				c->edge_cs_cap = need;
+				else
+				{
+					(void)hipGetLastError();  // not an error: evaluate without the table
+					c->d_edge_cs = nullptr;
+				}
 			}
 			L.ec.cs = c->d_edge_cs;
 		}

@@ -267,7 +267,8 @@ int ebo_read_tracks_txt(const char* path, ebo_track_point* out, size_t cap, size
 	char line[512];
 	size_t count = 0;
 	int rc = EBO_OK;
-	while (count < cap && std::fgets(line, sizeof(line), fp))
+	size_t total = 0;  // records in the file, also those beyond cap
+	while (std::fgets(line, sizeof(line), fp))
 	{
 		char* end = nullptr;
 		const long long id = std::strtoll(line, &end, 10);
@@ -302,6 +303,11 @@ int ebo_read_tracks_txt(const char* path, ebo_track_point* out, size_t cap, size
 			rc = EBO_ERR_RANGE;
 			break;
 		}
+		++total;
+		if (count >= cap)
+		{
+			continue;  // counted, not stored: the caller learns how large a buffer the file needs
+		}
 		ebo_track_point& t = out[count++];
 		t.id = id;
 		t.t_us = static_cast<int64_t>(std::llround(v[0] * 1000000.0));
@@ -309,6 +315,11 @@ int ebo_read_tracks_txt(const char* path, ebo_track_point* out, size_t cap, size
 		t.y = v[2];
 	}
 	std::fclose(fp);
+	if (rc == EBO_OK && total > cap)
+	{
+		*n = total;  // never a silently truncated list: out holds the first cap records, *n says what is needed
+		return EBO_ERR_ARG;
+	}
 	*n = count;
 	return rc;
 }

@@ -47,6 +47,35 @@ def test_device_bucketing_equals_host_bucketing(ebo, orc, synth, monkeypatch, co
     np.testing.assert_allclose(d[2][0], ro, rtol=1e-9)
 
 
+@pytest.mark.parametrize("quantum_us", [1000, 50000])
+def test_quantised_timestamps_keep_results_and_time(ebo, orc, synth, monkeypatch, quantum_us):
+    """Recordings with quantised stamps (a simulator's frame times, a millisecond driver): hundreds to
+    thousands of events of a unit share ONE timestamp.  The closed-form canonical order of k_bucket_canon walks
+    a run of equal stamps once per record (O(run^2)); runs above 32 records take the bitonic network instead --
+    same unit tables, evaluations and images as the host counting sort, bit for bit, and no time cliff (a
+    whole window at one stamp used to cost ~10^5 serial LDS reads per thread)."""
+    import time
+    ev, offsets, gt = synth.make_stream(2, 4, n_events=50000)
+    ev = ev.copy()
+    ev["t_us"] = (ev["t_us"] // quantum_us) * quantum_us  # 50 ms windows: 50 stamps, or ONE stamp per window
+    results, took = {}, {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("EBO_BUCKET", mode)
+        with build(ebo, synth, 2, ev, offsets) as c:
+            c.set_windows(ev, offsets)
+            t0 = time.perf_counter()
+            c.set_windows(ev, offsets)
+            took[mode] = time.perf_counter() - t0
+            info = [[c.patch_info(p, w) for p in range(c.P)] for w in range(4)]
+            r, J = c.eval(gt * 0.5)
+            img = c.count_image(ebo.COUNT_WARPED, gt * 0.7)
+            results[mode] = (info, r, J, img)
+    h, d = results["host"], results["device"]
+    assert h[0] == d[0]
+    assert np.array_equal(h[1], d[1]) and np.array_equal(h[2], d[2]) and np.array_equal(h[3], d[3])
+    assert took["device"] < 0.05, took  # 200 k events: ~1 ms; the quadratic walk took tens of milliseconds per unit
+
+
 def test_device_resident_raw_events(ebo, orc, synth):
     """ebo_set_windows_device: the raw 24-byte records never touch the host path."""
     import ctypes

@@ -11,7 +11,17 @@ accepted by one and rejected by the other, the iteration counts drift apart and 
 to 1.4e-4 apart along the valley floor.  The CPU oracle does the same to ITSELF when its inputs
 move by 1e-12 relative (tests/test_host_solver_cpu.py::test_converged_solves_wander_at_noise_level,
 CPU only), so those windows have no answer to 1e-5.  profiles/r02_edge_tie_table.md is the
-per-window table (tools/edge_tie_table.py)."""
+per-window table (tools/edge_tie_table.py).
+
+What IS asserted on every window, wandering or not (round 3) -- the solvers' own equivalence:
+  * the ORACLE's objective (data terms + Huber-wrapped TV terms, feature_detector.cpp:357-396) at the HIP
+    flows equals the oracle's objective at its own flows to 1e-10 relative, and the HIP path's objective at
+    the oracle's flows equals the HIP objective at its own flows to 1e-10 (observed <= 1.2e-11 on the
+    wandering windows, 0 .. 4e-16 on the others; function_tolerance is 1e-12 per step): neither solver can
+    tell the two end points apart by the quantity it minimises;
+  * the gradient at the other side's end point is at the level the solver stopped at itself (max-norm
+    within 10x of its own, which is 0.4 .. 270 against costs of ~5e7: both stop on function_tolerance);
+  * 92 of the 100 walk the oracle's trajectory within 1e-5 (measured 93)."""
 import pytest
 
 import edge_ties
@@ -30,7 +40,18 @@ def test_reference_default_call_on_100_windows(ebo, orc, synth):
           % (len(same), ties, sum(r["active"] for r in rows), max(r["max_dflow"] for r in rows),
              max(r["final_cost_rel"] for r in rows)))
     assert all(r["value_ok"] for r in rows)
-    assert len(same) >= 88
+    assert len(same) >= 92  # measured 93 (round 2 and round 3)
+    # the test's own restatement of the objective is the oracle solver's: its cost at its own end point
+    assert max(r["cost_formula_rel"] for r in rows) <= 1e-13
+    # the solvers' own equivalence on EVERY window (the wandering ones are where it says something)
+    wander = [r for r in rows if r not in same]
+    print("wandering windows: " + ", ".join("%d (%d/%d its, flows %.1e apart, cross-cost %.1e / %.1e)"
+                                            % (r["window"], r["iterations"], r["iterations_oracle"], r["max_dflow"],
+                                               r["cross_cost_rel_oracle"], r["cross_cost_rel_hip"]) for r in wander))
+    for r in rows:
+        assert r["cross_cost_rel_oracle"] <= 1e-10 and r["cross_cost_rel_hip"] <= 1e-10, r
+        assert r["grad_oracle_at_hip"] <= 10.0 * max(r["grad_oracle_at_oracle"], 1.0), r
+        assert r["grad_hip_at_oracle"] <= 10.0 * max(r["grad_hip_at_hip"], 1.0), r
     # every window, also the ones whose end-game differs: the same minimum
     assert max(r["final_cost_rel"] for r in rows) <= 1e-9
     assert max(r["max_dflow"] for r in rows) <= 1e-3

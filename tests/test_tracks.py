@@ -56,6 +56,19 @@ def test_trajectory_txt_real_timestamps_and_errors(tmp_path, ebo):
     assert ei.value.code == ebo.ERR_RANGE
     with pytest.raises(ebo.EboError):
         ebo.write_tracks_txt(tmp_path / "no" / "such" / "dir.txt", pts)
+    # a file with more records than the buffer: never a silently truncated list -- the call says how many
+    # it holds (and keeps the first cap), the wrapper grows its buffer and reads them all
+    import ctypes as C
+    many = np.zeros(10, dtype=ebo.TRACK_DTYPE)
+    many["id"] = np.arange(10)
+    many["t_us"] = 1000 * np.arange(10)
+    longer = tmp_path / "long.txt"
+    ebo.write_tracks_txt(longer, many)
+    out = np.zeros(4, dtype=ebo.TRACK_DTYPE)
+    n = C.c_size_t()
+    rc = ebo.lib().ebo_read_tracks_txt(str(longer).encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(4), C.byref(n))
+    assert rc == ebo.ERR_ARG and n.value == 10 and out["id"].tolist() == [0, 1, 2, 3]
+    assert np.array_equal(ebo.read_tracks_txt(longer, cap=4), many)
 
 
 @pytest.mark.parametrize("sizes", [[5, 12], [9, 0, 4]])
@@ -93,7 +106,9 @@ def test_allgather_tracks_single_rank_rccl(ebo):
         with pytest.raises(ebo.EboError) as ei:
             c.allgather_tracks(pts)
         assert ei.value.code == ebo.ERR_STATE  # no communicator yet
+        assert c.comm_size() == (0, 1)
         c.comm_init(ebo.comm_unique_id(), 0, 1)
+        assert c.comm_size() == (0, 1)
         got, counts = c.allgather_tracks(pts)
         assert counts.tolist() == [37] and np.array_equal(got, pts)
         got, counts = c.allgather_tracks(pts[:0])
@@ -103,4 +118,19 @@ def test_allgather_tracks_single_rank_rccl(ebo):
         rc = ebo.lib().ebo_allgather_tracks(c._h, pts.ctypes.data_as(C.c_void_p), C.c_size_t(37),
                                             out.ctypes.data_as(C.c_void_p), C.c_size_t(5), C.byref(n), None)
         assert rc == ebo.ERR_ARG and n.value == 37 and not out["id"].any()
+        # the counts collective alone (what sizes the buffer), and the reduce of SURVEY 8(e)'s final image
+        cnt = np.zeros(1, dtype=np.uint64)
+        assert ebo.lib().ebo_allgather_track_counts(c._h, C.c_size_t(37), C.byref(n), cnt.ctypes.data_as(C.c_void_p)) == 0
+        assert n.value == 37 and cnt.tolist() == [37]
+        import torch
+        a = torch.arange(1000, dtype=torch.float64, device="cuda")
+        b = torch.zeros_like(a)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.reduce_sum_device(a.data_ptr(), b.data_ptr(), 1000, root=0)
+        c.synchronize()
+        assert torch.equal(a, b)
+        b.zero_()
+        c.reduce_sum_device(a.data_ptr(), b.data_ptr(), 1000, root=-1)  # all-reduce
+        c.synchronize()
+        assert torch.equal(a, b)
         c.comm_destroy()
