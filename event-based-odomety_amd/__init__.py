@@ -137,6 +137,11 @@ def lib():
         _lib.ebo_last_error.argtypes = [C.c_void_p]
         _lib.ebo_destroy.restype = None
         _lib.ebo_destroy.argtypes = [C.c_void_p]
+        _lib.ebo_lm_destroy.restype = None
+        _lib.ebo_lm_destroy.argtypes = [C.c_void_p]
+        _lib.ebo_lm_request.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.ebo_lm_supply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ebo_lm_result.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -179,6 +184,56 @@ def optimizer_default_solver(**kw):
             raise AttributeError(key)
         setattr(o, key, val)
     return o
+
+
+class HostSolver:
+    """ebo_lm_*: the host LM of EBO_SOLVE_GLOBAL as a resumable state machine (request -> evaluate -> supply)."""
+
+    DONE, NEED_JACOBIAN, NEED_VALUE = 0, 1, 2
+
+    def __init__(self, npx, npy, active, tv_weight=1e3, tv_huber=10.0, opts=None):
+        self.P = int(npx) * int(npy)
+        active = np.ascontiguousarray(active, dtype=np.uint8).reshape(self.P)
+        self._opts = opts if opts is not None else default_solver()
+        h = C.c_void_p()
+        rc = lib().ebo_lm_create(int(npx), int(npy), _vp(active), C.c_double(tv_weight), C.c_double(tv_huber),
+                                 C.byref(self._opts), C.byref(h))
+        if rc:
+            raise EboError(rc, "ebo_lm_create")
+        self._h = h
+
+    def request(self):
+        flows = np.zeros((self.P, 2))
+        rc = lib().ebo_lm_request(self._h, _dp(flows))
+        if rc < 0:
+            raise EboError(rc, "ebo_lm_request")
+        return rc, flows
+
+    def supply(self, r, jac=None):
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(self.P)
+        j = None if jac is None else np.ascontiguousarray(jac, dtype=np.float64).reshape(self.P, 2)
+        rc = lib().ebo_lm_supply(self._h, _dp(r), _dp(j) if j is not None else None)
+        if rc:
+            raise EboError(rc, "ebo_lm_supply")
+
+    def result(self):
+        flows = np.zeros((self.P, 2))
+        s = Summary()
+        rc = lib().ebo_lm_result(self._h, _dp(flows), C.byref(s))
+        if rc:
+            raise EboError(rc, "ebo_lm_result")
+        return flows, s
+
+    def close(self):
+        if self._h:
+            lib().ebo_lm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def window_ref_time(t_first_us, t_last_us):

@@ -2101,25 +2101,27 @@ __global__ void k_count_stray(const uint64_t* __restrict__ events, const Unit* _
 __global__ void __launch_bounds__(256) k_stream_yardstick(const uint4* __restrict__ events16, size_t nEv16,
 														   double2* __restrict__ image16, size_t nPx16)
 {
-	const size_t perE = (nEv16 + gridDim.x - 1) / gridDim.x, perP = (nPx16 + gridDim.x - 1) / gridDim.x;
-	const size_t e0 = perE * blockIdx.x, e1 = min(e0 + perE, nEv16);
+	// grid-stride over both streams at once, four 16-byte loads and four 16-byte stores in flight per lane:
+	// reads and writes are interleaved at instruction level everywhere on the chip
+	const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+	const size_t first = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	const size_t n = nEv16 > nPx16 ? nEv16 : nPx16;
 	unsigned int x = 0;
-	for (size_t i = e0 + threadIdx.x; i < e1; i += 4 * blockDim.x)
+	const double2 zero = make_double2(0.0, 0.0);
+	for (size_t i = first; i < n; i += 4 * stride)
 	{
-		// four independent 16-byte loads in flight per lane
-		const uint4 a = events16[i];
-		const uint4 b = (i + blockDim.x < e1) ? events16[i + blockDim.x] : make_uint4(0, 0, 0, 0);
-		const uint4 c = (i + 2 * blockDim.x < e1) ? events16[i + 2 * blockDim.x] : make_uint4(0, 0, 0, 0);
-		const uint4 d = (i + 3 * blockDim.x < e1) ? events16[i + 3 * blockDim.x] : make_uint4(0, 0, 0, 0);
+		const size_t i1 = i + stride, i2 = i + 2 * stride, i3 = i + 3 * stride;
+		const uint4 a = (i < nEv16) ? events16[i] : make_uint4(0, 0, 0, 0);
+		const uint4 b = (i1 < nEv16) ? events16[i1] : make_uint4(0, 0, 0, 0);
+		const uint4 c = (i2 < nEv16) ? events16[i2] : make_uint4(0, 0, 0, 0);
+		const uint4 d = (i3 < nEv16) ? events16[i3] : make_uint4(0, 0, 0, 0);
+		if (i < nPx16) image16[i] = zero;
+		if (i1 < nPx16) image16[i1] = zero;
+		if (i2 < nPx16) image16[i2] = zero;
+		if (i3 < nPx16) image16[i3] = zero;
 		x ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
 	}
 	asm volatile("" ::"v"(x));  // the loads are used
-	const double v = 0.0;
-	const size_t p0 = perP * blockIdx.x, p1 = min(p0 + perP, nPx16);
-	for (size_t i = p0 + threadIdx.x; i < p1; i += blockDim.x)
-	{
-		image16[i] = make_double2(v, v);
-	}
 }
 
 // The final image of warped events (feature_detector.cpp:433-463) of windows whose patches are SHARDED

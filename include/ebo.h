@@ -225,6 +225,30 @@ int ebo_solve(ebo_ctx* ctx, const ebo_solver_opts* o, double* flows_out, ebo_sum
 int ebo_solve_device(ebo_ctx* ctx, const ebo_solver_opts* o, double* d_flows_out,
 					 int32_t* d_stats);
 
+/* The host solver of EBO_SOLVE_GLOBAL -- the trust-region LM over ONE problem per window (a contrast data
+ * term per active patch + Huber-wrapped total-variation terms between grid neighbours, R2 :357-414) -- as the
+ * resumable state machine ebo_solve drives internally, for a caller that must put something BETWEEN "evaluate"
+ * and "step".  SURVEY 8(e), reference-faithful TV mode across GPUs: every rank evaluates the data terms of its
+ * patch rows (ebo_set_patches + ebo_eval), ONE all-gather of (r, J0, J1) = 24 B per patch per evaluation, and
+ * the same solver replicated on every rank takes the same step (tests/test_gpu_multiprocess.py: equal to the
+ * one-process ebo_solve bit for bit).
+ *   ebo_lm_create: npx x npy grid, active[p] != 0 iff patch p has a data term (n_events > min_events),
+ *     tv_weight / tv_huber = DetectorParams::compensateTVweight / compensateTVHuberLoss, o as ebo_solve.
+ *   ebo_lm_request(flows [P][2]): the point the data terms are wanted at; returns 1 = residuals AND Jacobians
+ *     wanted, 2 = residuals only, 0 = the solve has finished (flows untouched), < 0 = EBO_ERR_*.
+ *   ebo_lm_supply(r [P], jac [P][2]): the data terms at that point (inactive patches ignored; jac may be NULL
+ *     when only residuals were wanted).  EBO_ERR_STATE after the solve has finished.
+ *   ebo_lm_result: the solution (the lowest-cost point visited, as Ceres returns it) and the summary
+ *     (num_evals_* count evaluation ROUNDS of the whole problem here).
+ * Host only: no device is touched, no context is needed. */
+typedef struct ebo_lm ebo_lm;
+int ebo_lm_create(int npx, int npy, const uint8_t* active, double tv_weight, double tv_huber, const ebo_solver_opts* o,
+				  ebo_lm** out);
+int ebo_lm_request(ebo_lm* lm, double* flows);
+int ebo_lm_supply(ebo_lm* lm, const double* r, const double* jac);
+int ebo_lm_result(const ebo_lm* lm, double* flows, ebo_summary* summary);
+void ebo_lm_destroy(ebo_lm* lm);
+
 /* Integer-valued event-count images (CV_64F in the reference), host out
  * [Wn][image_h][image_w].  aux: EBO_COUNT_WARPED -> host flows [Wn][P][2];
  * EBO_COUNT_FIELD -> host float32 field [Wn][image_h][image_w][2]; else NULL. */

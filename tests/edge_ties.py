@@ -12,33 +12,6 @@ same flows."""
 import numpy as np
 
 
-def zero_flow_tie_mask(orc, ev, prm, P, n_perm=4, seed=0):
-    """Patches whose edge-loss Jacobian at EXACTLY zero flow is decided by ROUNDING, found from the oracle
-    alone.  At zero flow all events sit on integer positions, symmetric pixels have mathematically equal
-    eigenvalues, and which of them is a window's argmax -- hence the Jacobian, not the value -- depends on the
-    last bits of the image sums: one rounding per event IN LIST ORDER in the reference.  So the oracle is
-    evaluated again with the events of the window in other orders (first and last event kept: they define
-    the reference times): a patch whose Jacobian changes with the order of a sum is a patch the reference
-    itself does not define to better than a tie-break.  Independent of the device."""
-    z = np.zeros((P, 2))
-    _, J0, active, _ = orc.window_eval(ev, prm, z)
-    mask = np.zeros(P, dtype=bool)
-    rng = np.random.default_rng(seed)
-    n = len(ev)
-    for k in range(n_perm):
-        order = np.arange(n)
-        if n > 3:
-            mid = order[1:-1].copy()
-            if k == 0:
-                mid = mid[::-1]
-            else:
-                rng.shuffle(mid)
-            order[1:-1] = mid
-        _, Jp, _, _ = orc.window_eval(ev[order], prm, z)
-        mask |= (np.abs(Jp - J0) > 1e-8 * np.abs(J0) + 1e-7).any(axis=1)
-    return mask & active.astype(bool), J0, active.astype(bool)
-
-
 def global_objective(r, J, active, flows, npx, npy, tv_weight, tv_huber):
     """Cost and gradient of the problem FeatureDetector::compensateEventsContrast hands to Ceres
     (feature_detector.cpp:357-396) at `flows` [P][2], from the data terms' residuals r [P] and Jacobians

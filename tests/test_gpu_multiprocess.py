@@ -53,6 +53,30 @@ def test_sharded_device_solve_gather_and_final_image_equal_one_process(tmp_path,
     assert np.all(first[~act] == 0)
 
 
+@pytest.mark.parametrize("world,loss", [(2, 0), (3, 0), (3, 1)])
+def test_reference_faithful_tv_mode_across_ranks_equals_ebo_solve(tmp_path, ebo, synth, world, loss):
+    """SURVEY 8(e) "Collective", reference-faithful mode: the reference's ONE problem per window (data terms +
+    TV terms between neighbouring patches, feature_detector.cpp:357-414) with the data terms evaluated where the
+    patches live -- every rank its grid rows, on the device -- ONE all-gather of (r, J0, J1) per LM evaluation,
+    and the resumable host solver of the ABI (ebo_lm_*) replicated on every rank.  The flows of every rank equal
+    the one-process ebo_solve(EBO_SOLVE_GLOBAL) of the same window BIT FOR BIT (reference defaults: 12 x 9 grid of
+    equal 20 x 20 patches; edge loss = the reference's own, variance loss = the north-star objective)."""
+    res = _torchrun(world, 29560 + world + 10 * loss, os.path.join(HERE, "mp_gpu_tv_worker.py"), tmp_path, 0, loss)
+    assert res.returncode == 0, res.stderr[-3000:]
+    cfg = synth.CONFIGS[0]
+    ev, _ = synth.make_window(0, n_events=min(cfg["events"], 30000))
+    with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0], patch_h=cfg["patch"][1],
+                     loss=loss, max_events=len(ev)) as c:
+        c.set_window(ev)
+        whole, summ = c.solve(ebo.default_solver())
+    for r in range(world):
+        flows = np.load(os.path.join(str(tmp_path), "tvflows_rank%d.npy" % r))
+        its, term, evals = np.load(os.path.join(str(tmp_path), "tvstats_rank%d.npy" % r)).tolist()
+        assert np.array_equal(flows, whole[0]), np.abs(flows - whole[0]).max()
+        assert its == summ[0].iterations and term == summ[0].termination and evals >= its
+    assert np.abs(whole[0]).max() > 0.05
+
+
 @pytest.mark.parametrize("extra", [[], ["--replicas", "--windows", "4"]])
 def test_bench_runs_at_two_ranks_without_a_launcher(extra):
     """`python bench.py --gpus 2` as the driver calls it (no torchrun around it): it spawns its own

@@ -52,9 +52,20 @@ def test_random_windows_match_the_oracle(ebo, orc, seed):
                 tol = 1e-9 if loss == ebo.LOSS_VARIANCE else 1e-8
                 np.testing.assert_allclose(r[0], ro, rtol=1e-9, atol=1e-9)
                 if loss == ebo.LOSS_EDGE and scale == 0.0:
-                    # exactly zero flow: events on integer positions, exact ties of the window
-                    # maxima, the argmax (and with it the Jacobian) is decided by rounding noise
-                    # in the reference too; see test_edge_jacobian_at_exact_ties
+                    # Exactly zero flow, where every solve starts: events on integer positions, symmetric pixels
+                    # with mathematically EQUAL eigenvalues; which of them is a window's argmax -- and with it the
+                    # Jacobian, not the value -- is decided by the last bits of the image sums: k roundings for a
+                    # pixel that k events reach in the reference, one exact sum on the device (the reference's
+                    # own result does not depend on the order of its event list there -- every event adds the
+                    # same 49 weights -- so no oracle-side experiment singles those patches out; measured).
+                    # No blanket skip: every patch is compared by the criterion of
+                    # test_edge_jacobian_at_exact_ties; the patches that differ ARE the carve-out, and a window
+                    # may have at most one of them, or 5 % of its active patches (measured: 6 of 721 patches over
+                    # 54 windows); all others must agree to the tolerance of every other flow.
+                    act = active.astype(bool)
+                    tie = (np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-7).any(axis=1) & act
+                    assert tie.sum() <= max(1, int(0.05 * act.sum())), (int(tie.sum()), int(act.sum()))
+                    np.testing.assert_allclose(J[0][~tie], Jo[~tie], rtol=tol, atol=1e-7)
                     continue
                 np.testing.assert_allclose(J[0], Jo, rtol=tol, atol=1e-7)
             if loss == ebo.LOSS_VARIANCE:

@@ -104,3 +104,41 @@ def test_converged_solves_wander_at_noise_level(orc, synth):
             if d > 1e-5 or sg.iterations != sb.iterations:
                 moved += 1
     assert moved >= 3
+
+
+def test_abi_host_solver_state_machine(ebo, orc, synth):
+    """ebo_lm_* of the C ABI (the same HostLm, exported for callers that put a collective between "evaluate" and
+    "step": SURVEY 8(e)'s reference-faithful TV mode across GPUs), driven on the CPU with the oracle's data terms:
+    the oracle solver's flows, iteration count and termination; argument and state errors."""
+    ev, _ = synth.make_window(0, n_events=2500)
+    prm = orc.default_params(loss=0, tv_weight=1e3)
+    npx, npy = orc.grid(prm)
+    P = npx * npy
+    _, _, active, _ = orc.window_eval(ev, prm, np.zeros((P, 2)), want_jac=False)
+    opts = ebo.default_solver(max_num_iterations=50)
+    with ebo.HostSolver(npx, npy, active, tv_weight=prm.tv_weight, tv_huber=prm.tv_huber, opts=opts) as lm:
+        rounds = 0
+        while True:
+            what, flows = lm.request()
+            if what == ebo.HostSolver.DONE:
+                break
+            again, flows2 = lm.request()  # asking twice changes nothing
+            assert again == what and np.array_equal(flows, flows2)
+            r, J, _, _ = orc.window_eval(ev, prm, flows, want_jac=(what == ebo.HostSolver.NEED_JACOBIAN))
+            if what == ebo.HostSolver.NEED_JACOBIAN:
+                with pytest.raises(ebo.EboError) as err:  # a Jacobian was asked for
+                    lm.supply(r, None)
+                assert err.value.code == ebo.ERR_ARG
+            lm.supply(r, J)
+            rounds += 1
+        out, summ = lm.result()
+        with pytest.raises(ebo.EboError) as err:  # the solve has finished
+            lm.supply(np.zeros(P), np.zeros((P, 2)))
+        assert err.value.code == ebo.ERR_STATE
+    fo, _, so = orc.compensate_events_contrast(ev, prm, orc.default_solver(max_num_iterations=50), want_image=False)
+    assert np.abs(out - fo).max() <= 1e-9
+    assert summ.iterations == so.iterations and summ.termination == so.termination
+    assert rounds == summ.num_evals_cost + summ.num_evals_jac
+    assert summ.final_cost == pytest.approx(so.final_cost, rel=1e-9)
+    with pytest.raises(ebo.EboError):
+        ebo.HostSolver(0, 3, np.zeros(0))
