@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 ebo = importlib.import_module("event-based-odomety_amd")
 synth = importlib.import_module("event-based-odomety_amd.synth")
 
-KEYS = ("EBO_EVAL_IMPL", "EBO_EVAL_ROT", "EBO_LDS_KB", "EBO_EVAL_TILES", "EBO_EVAL_BLOCK")
+KEYS = ("EBO_EVAL_IMPL", "EBO_EVAL_ROT", "EBO_LDS_KB", "EBO_EVAL_TILES", "EBO_EVAL_BLOCK", "EBO_EVAL_DEAL")
 
 
 def main():

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of a round on one MI355X (run through gpurun from the repo root):
-#   bash event-based-odomety_amd/tools/profile_round.sh r02
+#   bash event-based-odomety_amd/tools/profile_round.sh r03
 # Writes summaries under gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
 # Counter passes are separate runs (--pmc never together with traces), the program itself follows `--`.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -52,6 +52,15 @@ for cfg in "2 1536" "3 512" "4 72"; do
   $S k_count $O/cf_$n $O/cw_$n $O/cs_$n > $O/${TAG}_pmc_count_$n.txt
 done
 echo "[5/6] count kernels done"
+
+# 5b. the N > 1 default workload's kernel (k_solve_independent, config-4 shard of one GPU) at N = 1: kernel stats + HBM traffic
+C4="$PY $R/bench.py --workload c4 --steps 5 --warmup 1 --cpu-seconds 1"
+rocprofv3 --kernel-trace --stats -d $O/ks_c4 --output-format csv -- $C4 > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
+cp $O/ks_c4/*/*kernel_stats.csv $O/${TAG}_bench_c4_1gpu_kernel_stats.csv 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE -d $O/c4f --output-format csv -- $C4 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/c4w --output-format csv -- $C4 > /dev/null 2>&1
+$S k_solve_independent $O/c4f $O/c4w > $O/${TAG}_pmc_k_solve_independent_c4.txt
+echo "[5b] c4 solve kernel done"
 
 # 6. the N > 1 code paths rehearsed on this one GPU (2 ranks share it, collectives over gloo)
 cd $R
