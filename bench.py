@@ -175,16 +175,20 @@ def cpu_baseline_all_cores(cfg_idx, seconds):
 # --------------------------------------------------------------------------------------------
 # launcher
 # --------------------------------------------------------------------------------------------
-LDS_PEAK_GOPS = {"ds_add_u64_random": 3479.0, "ds_read_b64_random": 5741.0}  # measured, MI355X, 4 workgroups per CU
+LDS_PEAK_GOPS = {"ds_add_u64_random": 3479.0, "ds_read_b64_random": 5741.0}  # round-2 microbenchmark (fallback only)
 
 
-def lds_roofline(event_evals, kern_ms):
+def lds_roofline(event_evals, kern_ms, rates=None):
     """The LDS-side bound of one value+Jacobian evaluation launch: time the scatter's atomics and the
-    gather's reads would take at the microbenchmarked LDS rates, against the measured launch."""
-    min_ms = (49.0 * event_evals / (LDS_PEAK_GOPS["ds_add_u64_random"] * 1e9)
-              + 49.0 * event_evals / (LDS_PEAK_GOPS["ds_read_b64_random"] * 1e9)) * 1e3
-    return {"ops_per_event": {"ds_add_u64": 49, "ds_read_b64": 49}, "peak_Gops": LDS_PEAK_GOPS,
-            "min_ms": min_ms, "frac": min_ms / kern_ms, "source": "event-based-odomety_amd/tools/microbench/lds_atomics.hip"}
+    gather's reads would take at the LDS rates measured IN THIS RUN on this GPU (ebo_lds_rates: the
+    loops of tools/microbench/lds_atomics.hip at random addresses), against the measured launch."""
+    peaks = dict(LDS_PEAK_GOPS) if rates is None else {"ds_add_u64_random": rates[0], "ds_read_b64_random": rates[1]}
+    min_ms = (49.0 * event_evals / (peaks["ds_add_u64_random"] * 1e9)
+              + 49.0 * event_evals / (peaks["ds_read_b64_random"] * 1e9)) * 1e3
+    return {"ops_per_event": {"ds_add_u64": 49, "ds_read_b64": 49}, "peak_Gops": peaks,
+            "min_ms": min_ms, "frac": min_ms / kern_ms,
+            "source": "measured in this run (ebo_lds_rates)" if rates is not None
+            else "event-based-odomety_amd/tools/microbench/lds_atomics.hip (round-2 figures)"}
 
 
 def _free_port():
@@ -572,6 +576,12 @@ def main():
 
     # ---- dominant kernel: average launch duration by HIP events on ITS stream -----------------
     kern_ms = timed(kernel_fn, max(3, args.steps))
+    lds_rates = None
+    if rank == 0 and workload != "c4":
+        try:
+            lds_rates = ctx.lds_rates()  # the LDS rates the kernel is priced against, measured in this run
+        except Exception:
+            lds_rates = None
     achieved = BYTES_PER_EVENT_EVAL * units_per_step / (kern_ms * 1e-3) / 1e9
 
     if workload == "replicas" and rank == 0:
@@ -845,8 +855,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             for t in json.load(open(tpath)).get("kernels", []):
-                if (t.get("kernel") == roof_kernel and t.get("workload") == cfg["name"]
-                        and t.get("windows") == config.get("windows_per_gpu_per_step")):
+                same = (t.get("c4_windows_per_gpu") == args.c4_windows) if workload == "c4" else (
+                    t.get("windows") == config.get("windows_per_gpu_per_step"))
+                if t.get("kernel") == roof_kernel and t.get("workload") == cfg["name"] and same:
                     traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
         value = total_units * args.steps / dt / 1e6
         line = {
@@ -864,7 +875,7 @@ def main():
                          # what does bind it: 49 64-bit LDS atomics + 49 64-bit LDS reads per event-evaluation
                          # against the chip-wide rates of tools/microbench/lds_atomics.hip on this GPU
                          # (ds_add_u64 and ds_read_b64 at random addresses)
-                         "lds": lds_roofline(units_per_step, kern_ms) if workload != "c4" else None},
+                         "lds": lds_roofline(units_per_step, kern_ms, lds_rates) if workload != "c4" else None},
             "cpu_baseline": base,
             "extras": extras,
         }

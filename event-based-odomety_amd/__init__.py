@@ -524,6 +524,12 @@ class Context:
         keys = ("units", "events", "box_pixels", "eigen_pixels", "nms_windows", "argmax_entries")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def lds_rates(self):
+        """diagnostic: (G atomics/s, G reads/s) of 64-bit LDS operations at random addresses, measured now"""
+        out = (C.c_double * 2)()
+        self._check(lib().ebo_lds_rates(self._h, out))
+        return float(out[0]), float(out[1])
+
     def stream_yardstick_device(self, d_image):
         """diagnostic: the bytes of a count-image launch with no work; returns the bytes moved"""
         n = C.c_uint64()

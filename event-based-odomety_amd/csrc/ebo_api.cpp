@@ -1692,6 +1692,57 @@ int ebo_edge_work_stats(ebo_ctx* c, const double* d_flows, int want_jac, uint64_
 	return rc;
 }
 
+int ebo_lds_rates(ebo_ctx* c, double* gops)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (!gops)
+	{
+		return c->fail(EBO_ERR_ARG, "null output");
+	}
+	(void)hipSetDevice(c->prm.device);
+	int cus = 256;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, c->prm.device) == hipSuccess && prop.multiProcessorCount > 0)
+	{
+		cus = prop.multiProcessorCount;
+	}
+	const int blocks = 4 * cus, iters = 2048;
+	int rc = ensure_aux(c, static_cast<size_t>(blocks) * sizeof(double));
+	if (rc)
+	{
+		return rc;
+	}
+	for (int kind = 0; kind < 2 && rc == EBO_OK; ++kind)
+	{
+		if (launch_lds_rate(kind == 0, blocks, 16, static_cast<double*>(c->d_aux), c->stream))  // warm-up
+		{
+			return c->fail(EBO_ERR_HIP, "k_lds_rate launch failed");
+		}
+		double best = 0.0;
+		for (int rep = 0; rep < 3 && rc == EBO_OK; ++rep)
+		{
+			rc = c->hip(hipEventRecord(c->ev0, c->stream), "hipEventRecord");
+			if (rc == EBO_OK && launch_lds_rate(kind == 0, blocks, iters, static_cast<double*>(c->d_aux), c->stream))
+			{
+				return c->fail(EBO_ERR_HIP, "k_lds_rate launch failed");
+			}
+			if (rc == EBO_OK) rc = c->hip(hipEventRecord(c->ev1, c->stream), "hipEventRecord");
+			if (rc == EBO_OK) rc = c->hip(hipEventSynchronize(c->ev1), "hipEventSynchronize");
+			float ms = 0.0f;
+			if (rc == EBO_OK) rc = c->hip(hipEventElapsedTime(&ms, c->ev0, c->ev1), "hipEventElapsedTime");
+			if (rc == EBO_OK && ms > 0.0f)
+			{
+				best = std::max(best, static_cast<double>(blocks) * 256.0 * iters / (ms * 1e-3) / 1e9);
+			}
+		}
+		gops[kind] = best;
+	}
+	return rc;
+}
+
 int ebo_stream_yardstick_device(ebo_ctx* c, double* d_image, uint64_t* bytes)
 {
 	if (!c)

@@ -142,6 +142,7 @@ struct EdgeLaunch
 	EvalConsts c;
 	EdgeConsts ec;
 };
+int launch_lds_rate(int atomic, int blocks, int iters, double* d_sink, void* stream);
 int launch_stream_yardstick(const uint64_t* d_events, size_t n_events, double* d_image, size_t n_pixels, void* stream);
 int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,
 					   const int32_t* d_dtwin, const double* d_flows, double* d_image, const EvalConsts& c, void* stream);

@@ -2094,6 +2094,45 @@ __global__ void k_count_stray(const uint64_t* __restrict__ events, const Unit* _
 	}
 }
 
+// LDS rates at random addresses, measured in the run that quotes them (bench.py's roofline.lds; the same loops as
+// tools/microbench/lds_atomics.hip, patterns "random"): every lane issues `iters` 64-bit LDS atomic adds (ATOMIC) or
+// 64-bit LDS reads at pseudo-random slots of a 32 KB array, 4 workgroups of 256 lanes per CU.
+template <bool ATOMIC>
+__global__ void __launch_bounds__(256) k_lds_rate(double* __restrict__ sink, int iters)
+{
+	constexpr int kElems = 4096;
+	__shared__ unsigned long long cell[kElems];
+	for (int i = threadIdx.x; i < kElems; i += blockDim.x)
+	{
+		cell[i] = static_cast<unsigned long long>(i);
+	}
+	__syncthreads();
+	unsigned rnd = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+	unsigned long long acc = 0;
+	for (int it = 0; it < iters; ++it)
+	{
+		rnd = rnd * 1664525u + 1013904223u;
+		const unsigned a = (rnd >> 10) & (kElems - 1);
+		if (ATOMIC)
+		{
+			atomicAdd(&cell[a], 1ull);
+		}
+		else
+		{
+			acc += cell[a];
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < kElems; i += blockDim.x)
+	{
+		acc += cell[i];
+	}
+	if (acc == 0x0123456789abcdefull)  // never: keeps the loads and the adds alive
+	{
+		sink[blockIdx.x] = 1.0;
+	}
+}
+
 // Yardstick of the count-image kernels (bench.py, diagnostic): the same bytes with no work -- every packed
 // event read once with 16-byte loads, every image pixel written once with 16-byte stores -- by 2048
 // workgroups that each take a contiguous slice of both.  What this reaches on the chip is what "100 %"
@@ -3333,6 +3372,20 @@ int launch_bucket(const BucketLaunch& L, void* stream)
 	Rec24 r;
 	r.p = static_cast<const RawEvent*>(L.d_raw);
 	return launch_bucket_t(L, r, s);
+}
+
+int launch_lds_rate(int atomic, int blocks, int iters, double* d_sink, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (atomic)
+	{
+		hipLaunchKernelGGL(k_lds_rate<true>, dim3(blocks), dim3(256), 0, s, d_sink, iters);
+	}
+	else
+	{
+		hipLaunchKernelGGL(k_lds_rate<false>, dim3(blocks), dim3(256), 0, s, d_sink, iters);
+	}
+	return check_launch();
 }
 
 int launch_stream_yardstick(const uint64_t* d_events, size_t n_events, double* d_image, size_t n_pixels, void* stream)

@@ -372,6 +372,12 @@ int ebo_route_events(ebo_ctx* ctx, int n_patches, const double* rects, const uin
  * evaluation's (r, J) go to the context's own result buffer. */
 int ebo_edge_work_stats(ebo_ctx* ctx, const double* d_flows, int want_jac, uint64_t* out);
 
+/* Diagnostic (bench.py's roofline.lds): the chip-wide rates of 64-bit LDS atomic adds (gops[0]) and 64-bit LDS reads
+ * (gops[1]) at random addresses, in 1e9 operations per second, measured NOW on the context's device with the loops
+ * of tools/microbench/lds_atomics.hip (4 workgroups of 256 lanes per CU, 2048 operations per lane, best of three):
+ * the rates the scatter and the gather pass of the variance evaluation are priced against.  Synchronous. */
+int ebo_lds_rates(ebo_ctx* ctx, double* gops);
+
 /* Diagnostic (bench.py): the traffic of ebo_count_image_device with no work -- every packed event of the
  * loaded windows read once (16-byte loads), every pixel of d_image [Wn][image_h][image_w] written once
  * (16-byte stores, all 0.0) -- as the in-run yardstick of the HBM-bound count kernels: what a plain stream
