@@ -58,6 +58,9 @@ class TrackedPatches
 		p.device = device;
 		p.image_w = imageSize.width;
 		p.image_h = imageSize.height;
+		// the compensation grid is not used by the tracker path: keep it valid for images smaller than a patch
+		p.patch_w = std::min(p.patch_w, std::max(imageSize.width, 1));
+		p.patch_h = std::min(p.patch_h, std::max(imageSize.height, 1));
 		if (ebo_create(&p, &ctx_) != EBO_OK)
 		{
 			throw std::runtime_error(std::string("tracker::TrackedPatches: ") + ebo_last_error(nullptr));
