@@ -161,10 +161,13 @@ int ensure_scratch(ebo_ctx* c, size_t bytes)
 // impl 1/2: the image is the bounding box of the warped events; one workgroup owns
 // `cap` pixels of LDS (default 32 KiB => 5 workgroups per CU) and walks larger boxes
 // in sequential sub-bands.  A full canvas row must fit.
-int image_capacity(ebo_ctx* c, int& capDoubles, size_t& lds)
+int image_capacity(ebo_ctx* c, int& capDoubles, size_t& lds, size_t defaultKb = 40)
 {
 	const size_t headerBytes = 160 * sizeof(double);
-	size_t kb = env_size("EBO_LDS_KB", 40);  // 40 KB: as fast as 32 at small flows, +5-8 % near convergence (fewer sub-bands); 48 and more cost occupancy
+	// 40 KB at three waves per SIMD (four workgroups per CU; the device-resident solve): as fast as 32 at small
+	// flows, +5-8 % near convergence (fewer sub-bands); 48 and more cost occupancy.  The batched evaluation
+	// runs four waves per SIMD and passes 31 KB: five 192-lane workgroups per CU.
+	size_t kb = env_size("EBO_LDS_KB", defaultKb);
 	size_t bytes = std::min<size_t>(std::max<size_t>(kb, 4) * 1024, kLdsBudget);
 	// keep at least 24 rows of the widest canvas where that fits
 	const size_t want = static_cast<size_t>(24) * 3 * c->max_rw * sizeof(double) + headerBytes;
@@ -455,7 +458,23 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	}
 	else
 	{
-		rc = image_capacity(c, L.cap_doubles, L.lds_bytes);
+		// Many units: k_eval3 runs four waves per SIMD (128 VGPRs), i.e. 16 waves per CU, and what a launch
+		// chooses is how to cut them into workgroups -- more, smaller workgroups overlap their barrier-separated
+		// passes better on the CU's one LDS, but each gets less of it, and a box that does not fit is counted in
+		// sequential sub-bands (every event warped again per sub-band).  By the canvas of the REGULAR patch (the
+		// geometry only, never the data: a window evaluates bit-identically alone and inside any batch):
+		//    canvas <= 32 KB (the reference's 20x20 patches, C3's 21x16): 7 workgroups of 128 lanes, 22 KB
+		//    larger (C2 30x22, C4 40x22):                                  4 workgroups of 256 lanes, 39 KB
+		// Measured against three waves per SIMD with four 192-lane workgroups of 40 KB (round 2), evaluation with
+		// Jacobian at flows 0 / 0.5 / 1.0 x ground truth: 20x20 patches of 139 events -23 / -19 / -13 % time,
+		// C3 -8.5 / -5.3 / +0.8 %, C2 -6.3 / -2.5 / -2.3 %, C4 -3.9 / -2.9 / -4.4 % (profiles/r03_eval3_waves4_ab.txt;
+		// 128 lanes x 19 KB: better still at small flows, +6 % at the ground truth of C3; 192 lanes x 31 KB:
+		// -2 ... -4 % everywhere at C3, but only -8 ... -11 % on the 20x20 patches).
+		const int nUnitsAll = std::max(1, static_cast<int>(c->n_flows()));
+		const int regW = c->custom_n ? c->max_rw : c->prm.patch_w, regH = c->custom_n ? c->max_rh : c->prm.patch_h;
+		const bool smallCanvas = static_cast<size_t>(9) * regW * regH * sizeof(double) <= 32 * 1024;
+		const int manyBlock = smallCanvas ? 128 : 256;
+		rc = image_capacity(c, L.cap_doubles, L.lds_bytes, nUnitsAll < 1024 ? 40 : (smallCanvas ? 22 : 39));
 		// Measured (tools/sweep_impl.py): one row band per unit is best at every batch size
 		// (each band workgroup pays the bounding-box pass over all events); with few units
 		// a 512-thread workgroup shortens the per-unit critical path (29 vs 46 us for one
@@ -467,7 +486,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		// workgroup, so the two regimes differ in the last bits: a window is bit-identical alone
 		// and inside a batch as long as both are on the same side of 1024 units.)
 		const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
-		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : 192));
+		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : manyBlock));
 		if (L.block < 64 || L.block > 512 || (L.block & 63))
 		{
 			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,512]");
