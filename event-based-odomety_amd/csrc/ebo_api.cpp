@@ -833,14 +833,20 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
 	L.impl = std::max(1, eval_impl());
-	int rc = image_capacity(c, L.cap_doubles, L.lds_bytes);
+	// k_solve_independent runs three waves per SIMD (152-166 VGPRs since round 3: one next_step() site in the
+	// solver; 205 and two waves before), i.e. 12 waves per CU.  By the canvas of the regular patch, as the
+	// batched evaluation does: up to 32 KB six workgroups of 128 lanes with 26 KB each, above that four of 192
+	// lanes with 39 KB (fewer sub-bands near convergence).  Measured against 128 lanes x 40 KB at two waves
+	// (tools/ab/solve_waves.sh): C3 x 64 windows 25.1 -> 21.8 ms, 256 windows of 20x20 patches 12.5 -> 9.5 ms,
+	// C2 x 64 8.4 -> 7.7 ms, C4 x 4 10.1 -> 9.1 ms.
+	const int regW = c->custom_n ? c->max_rw : c->prm.patch_w, regH = c->custom_n ? c->max_rh : c->prm.patch_h;
+	const bool smallCanvas = static_cast<size_t>(9) * regW * regH * sizeof(double) <= 32 * 1024;
+	int rc = image_capacity(c, L.cap_doubles, L.lds_bytes, smallCanvas ? 26 : 39);
 	if (rc)
 	{
 		return rc;
 	}
-	// 128 threads: 256 windows of C2 solve in 28 ms against 38 ms with 256 threads (192: 39 ms),
-	// 20x20 patches of 139 events in 13 ms against 22 ms
-	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", 128));
+	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", smallCanvas ? 128 : 192));
 	if (L.block < 64 || L.block > 512 || (L.block & 63))
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_SOLVE_BLOCK must be a multiple of 64 in [64,512]");

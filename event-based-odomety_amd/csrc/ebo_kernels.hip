@@ -1101,9 +1101,8 @@ struct LmUnit
 			lastSuccessful = true;
 			d0 = d1 = 0.0;
 			numInvalid = 0;
-			return next_step(o);
 		}
-		if (phase == 1)
+		else if (phase == 1)
 		{
 			evalsCost++;
 			candCost = 0.5 * r * r;
@@ -1141,8 +1140,9 @@ struct LmUnit
 			radius = radius / decreaseFactor;
 			decreaseFactor *= 2.0;
 			reuseDiagonal = true;
-			return next_step(o);
 		}
+		else
+		{
 		// phase 2: the Jacobian at the accepted point
 		f = r;
 		J0 = a;
@@ -1189,6 +1189,8 @@ struct LmUnit
 			seReference = seCandidate;
 			seAccRef = seAccCand;
 		}
+		}
+		// ONE copy of the loop's top (three inlined copies cost the kernels that hold this solver ~70 VGPRs)
 		return next_step(o);
 	}
 };
