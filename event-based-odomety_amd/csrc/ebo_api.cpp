@@ -471,18 +471,15 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		// 128 lanes x 19 KB: better still at small flows, +6 % at the ground truth of C3; 192 lanes x 31 KB:
 		// -2 ... -4 % everywhere at C3, but only -8 ... -11 % on the 20x20 patches).
 		const int nUnitsAll = std::max(1, static_cast<int>(c->n_flows()));
-		const int regW = c->custom_n ? c->max_rw : c->prm.patch_w, regH = c->custom_n ? c->max_rh : c->prm.patch_h;
+		const int regW = c->reg_rw, regH = c->reg_rh;
 		const bool smallCanvas = static_cast<size_t>(9) * regW * regH * sizeof(double) <= 32 * 1024;
 		const int manyBlock = smallCanvas ? 128 : 256;
 		rc = image_capacity(c, L.cap_doubles, L.lds_bytes, nUnitsAll < 1024 ? 40 : (smallCanvas ? 22 : 39));
 		// Measured (tools/sweep_impl.py): one row band per unit is best at every batch size
 		// (each band workgroup pays the bounding-box pass over all events); with few units
 		// a 512-thread workgroup shortens the per-unit critical path (29 vs 46 us for one
-		// 64-patch window); with many units smaller workgroups pack the CU better and waste fewer
-		// lanes in a unit's last round of events: 192 threads against 256, evaluation with
-		// Jacobian at flows 0 / 0.5 / 1.0 x ground truth: C2 +14 / +9 / +7 %, C3 +10 / +8 / +7 %,
-		// C4 +10 / +6 / +6 %, 20x20 patches of 139 events +28 / +25 / +23 % (128 threads: more at
-		// small flows, -12 % at C4 near convergence).  (The sums of a unit are reduced over the
+		// 64-patch window); with many units the smaller workgroups chosen above pack the CU better and
+		// waste fewer lanes in a unit's last round of events.  (The sums of a unit are reduced over the
 		// workgroup, so the two regimes differ in the last bits: a window is bit-identical alone
 		// and inside a batch as long as both are on the same side of 1024 units.)
 		const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
@@ -839,7 +836,7 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	// lanes with 39 KB (fewer sub-bands near convergence).  Measured against 128 lanes x 40 KB at two waves
 	// (tools/ab/solve_waves.sh): C3 x 64 windows 25.1 -> 21.8 ms, 256 windows of 20x20 patches 12.5 -> 9.5 ms,
 	// C2 x 64 8.4 -> 7.7 ms, C4 x 4 10.1 -> 9.1 ms.
-	const int regW = c->custom_n ? c->max_rw : c->prm.patch_w, regH = c->custom_n ? c->max_rh : c->prm.patch_h;
+	const int regW = c->reg_rw, regH = c->reg_rh;
 	const bool smallCanvas = static_cast<size_t>(9) * regW * regH * sizeof(double) <= 32 * 1024;
 	int rc = image_capacity(c, L.cap_doubles, L.lds_bytes, smallCanvas ? 26 : 39);
 	if (rc)
@@ -1314,6 +1311,8 @@ int ebo_create(const ebo_params* p, ebo_ctx** out)
 	}
 	c->grid_max_rw = c->max_rw;
 	c->grid_max_rh = c->max_rh;
+	c->reg_rw = p->patch_w;
+	c->reg_rh = p->patch_h;
 	const size_t nf = static_cast<size_t>(c->cap_windows) * c->P;
 	const size_t npix = static_cast<size_t>(c->cap_windows) * p->image_w * p->image_h;
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -132,6 +132,9 @@ struct ebo_ctx
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	int max_rw = 0, max_rh = 0;
 	int grid_max_rw = 0, grid_max_rh = 0;
+	// the REGULAR patch of the loaded units (the grid's patch size; of patches loaded by ebo_set_patches the
+	// smallest rect, which for a shard of a grid is the grid's regular patch): what the launch shapes follow
+	int reg_rw = 0, reg_rh = 0;
 	int custom_n = 0;  // > 0: units were loaded by ebo_set_patches (arbitrary rects)
 
 	int cur_patches() const { return custom_n ? custom_n : P; }

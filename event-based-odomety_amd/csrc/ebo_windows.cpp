@@ -256,6 +256,8 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	c->custom_n = 0;
 	c->max_rw = c->grid_max_rw;
 	c->max_rh = c->grid_max_rh;
+	c->reg_rw = c->prm.patch_w;
+	c->reg_rh = c->prm.patch_h;
 	return EBO_OK;
 }
 
@@ -605,6 +607,8 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 	c->custom_n = 0;
 	c->max_rw = c->grid_max_rw;
 	c->max_rh = c->grid_max_rh;
+	c->reg_rw = c->prm.patch_w;
+	c->reg_rh = c->prm.patch_h;
 	return EBO_OK;
 }
 
@@ -631,7 +635,7 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 	std::vector<Unit> units(n_patches);
 	std::vector<int64_t> utref(n_patches, 0), utmin(n_patches, 0), utmax(n_patches, 0);
 	c->h_packed.resize(total);
-	int mrw = 0, mrh = 0;
+	int mrw = 0, mrh = 0, lrw = 0x7fffffff, lrh = 0x7fffffff;
 	size_t base = 0;
 	for (int p = 0; p < n_patches; ++p)
 	{
@@ -659,6 +663,8 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 		u.flow_idx = static_cast<uint32_t>(p);
 		mrw = std::max(mrw, r[2]);
 		mrh = std::max(mrh, r[3]);
+		lrw = std::min(lrw, r[2]);
+		lrh = std::min(lrh, r[3]);
 		int64_t tu = 0;
 		if (n > 0 && !mid_timestamp(pe[0].t_us, pe[n - 1].t_us, tu))  // contrast_functor.h:18-20
 		{
@@ -728,6 +734,8 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 	c->custom_n = n_patches;
 	c->max_rw = mrw;
 	c->max_rh = mrh;
+	c->reg_rw = std::min(lrw, mrw);
+	c->reg_rh = std::min(lrh, mrh);
 	return EBO_OK;
 }
 
