@@ -408,6 +408,7 @@ int run_eval_edge(ebo_ctx* c, const double* d_flows, int want_jac, double* d_out
 	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
 	EdgeLaunch L;
 	L.d_modes = c->modes_active;
+	L.live = c->live_active;
 	L.d_flows = d_flows;
 	L.want_jac = (want_jac && !central) ? 1 : 0;
 	L.flow_sets = central ? 5 : 1;
@@ -439,6 +440,7 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	const bool central = want_jac && c->prm.grad == EBO_GRAD_CENTRAL;
 	EvalLaunch L;
 	L.d_modes = c->modes_active;
+	L.live = c->live_active;
 	L.d_events = c->d_events;
 	L.d_units = c->d_units;
 	L.n_units = static_cast<int>(c->units.size());
@@ -582,10 +584,64 @@ int ensure_device_modes(ebo_ctx* c, size_t nf)
 // One half of a pipelined lock-step round: slots [s0, s1) of the flows go up, the launch covers
 // every unit with the mode table `modes` (zero outside the half: those workgroups exit at once),
 // the half's results come back, and `done` marks the end; nothing here waits.
+// The running windows of slots [s0, s1) as a kernel-argument list (LiveWindows), if the context is a grid of
+// windows, the caller vouches for one mode per window (windowSlots == P) and at most kLiveMax are running.
+bool live_windows_of(const ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, int windowSlots, LiveWindows& live)
+{
+	static const bool noCompact = std::getenv("EBO_SOLVE_NO_COMPACT") != nullptr;
+	live.n = 0;
+	if (c->custom_n || c->P <= 0 || windowSlots != c->P || s0 % c->P != 0 || s1 % c->P != 0 || noCompact)
+	{
+		return false;
+	}
+	const size_t P = static_cast<size_t>(c->P);
+	live.upw = c->P + 1;
+	for (size_t w = s0 / P; w < s1 / P; ++w)
+	{
+		const unsigned char m = modes[w * P];
+		if (m != 0)
+		{
+			if (live.n == kLiveMax)
+			{
+				live.n = 0;
+				return false;
+			}
+			live.ent[live.n++] = static_cast<int>(w << 2) | m;
+		}
+	}
+	return live.n > 0;
+}
+
 int eval_begin(ebo_ctx* c, const double* flows, const unsigned char* modes, int which, size_t s0, size_t s1, bool wantJac,
-			   hipEvent_t done)
+			   hipEvent_t done, int windowSlots)
 {
 	const size_t nf = c->n_flows();
+	// A half that has thinned out to a few windows (the late rounds of a batch: most of a solve's ROUNDS, little of
+	// its work): a launch over every unit with a mode table, the half's flows up and its results down were
+	// ~0.6 MB and 27 k mostly empty workgroups per round for two live windows.  Up to kLiveMax live windows go
+	// as a list in the kernel arguments instead: workgroups for their units only, their mode in the list entry,
+	// flows read from and results written to the pinned buffers by the kernel itself -- one launch, no copy.
+	// (Windows of a grid context: P flow slots and P + 1 units each, one mode per window.)
+	{
+		LiveWindows live;
+		if (live_windows_of(c, modes, s0, s1, windowSlots, live))
+		{
+			const size_t P = static_cast<size_t>(c->P);
+			for (int k = 0; k < live.n; ++k)
+			{
+				const size_t w = static_cast<size_t>(live.ent[k] >> 2);
+				std::memcpy(c->pin_flows + 2 * w * P, flows + 2 * w * P, P * 2 * sizeof(double));
+			}
+			c->live_active = live;
+			const int rc = run_eval_device(c, c->pin_flows, wantJac, c->pin_out);
+			c->live_active.n = 0;
+			if (rc)
+			{
+				return rc;
+			}
+			return c->hip(hipEventRecord(done, c->stream), "compact round");
+		}
+	}
 	std::memcpy(c->pin_flows + 2 * s0, flows + 2 * s0, (s1 - s0) * 2 * sizeof(double));
 	hipError_t e = hipMemcpyAsync(c->d_flows + 2 * s0, c->pin_flows + 2 * s0, (s1 - s0) * 2 * sizeof(double),
 								  hipMemcpyHostToDevice, c->stream);
@@ -609,7 +665,7 @@ int eval_begin(ebo_ctx* c, const double* flows, const unsigned char* modes, int 
 }
 
 int eval_finish(ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, bool wantJac, double* r, double* jac,
-				hipEvent_t done)
+				hipEvent_t done, int windowSlots)
 {
 	int rc = c->hip(hipEventSynchronize(done), "round");
 	if (rc)
@@ -617,10 +673,15 @@ int eval_finish(ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, bo
 		return rc;
 	}
 	const double* h_out = c->pin_out;
+	const size_t run = windowSlots > 0 ? static_cast<size_t>(windowSlots) : 1;  // one mode per aligned run of slots
 	for (size_t i = s0; i < s1; ++i)
 	{
 		if (modes[i] == 0)
 		{
+			if (run > 1 && i % run == 0)
+			{
+				i += run - 1;  // a finished window: none of its slots is wanted
+			}
 			continue;
 		}
 		r[i] = h_out[3 * i];
@@ -633,13 +694,52 @@ int eval_finish(ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, bo
 	return EBO_OK;
 }
 
-int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const unsigned char* modes = nullptr)
+int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const unsigned char* modes = nullptr, int windowSlots = 0)
 {
 	const size_t nf = c->n_flows();
 	int rc = ensure_eval_staging(c, nf);
 	if (rc)
 	{
 		return rc;
+	}
+	// a batch of windows of which some have finished: the running ones as a list in the kernel arguments, flows and
+	// results through the pinned buffers (as in eval_begin)
+	LiveWindows live;
+	if (modes && live_windows_of(c, modes, 0, nf, windowSlots, live))
+	{
+		const size_t P = static_cast<size_t>(c->P);
+		for (int k = 0; k < live.n; ++k)
+		{
+			const size_t w = static_cast<size_t>(live.ent[k] >> 2);
+			std::memcpy(c->pin_flows + 2 * w * P, flows + 2 * w * P, P * 2 * sizeof(double));
+		}
+		c->live_active = live;
+		rc = run_eval_device(c, c->pin_flows, jac != nullptr, c->pin_out);
+		c->live_active.n = 0;
+		if (rc == EBO_OK)
+		{
+			rc = c->hip(hipStreamSynchronize(c->stream), "evaluation");
+		}
+		if (rc)
+		{
+			return rc;
+		}
+		const double* h = c->pin_out;
+		for (int k = 0; k < live.n; ++k)
+		{
+			const size_t w = static_cast<size_t>(live.ent[k] >> 2);
+			const bool wj = jac && (live.ent[k] & 3) == 2;
+			for (size_t i = w * P; i < (w + 1) * P; ++i)
+			{
+				r[i] = h[3 * i];
+				if (wj)
+				{
+					jac[2 * i] = h[3 * i + 1];
+					jac[2 * i + 1] = h[3 * i + 2];
+				}
+			}
+		}
+		return EBO_OK;
 	}
 	// Small rounds (a single window's LM round is 108 flows): the kernels read the flows from
 	// and write the results to the pinned buffers themselves; the round is one launch + one
@@ -721,7 +821,10 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 struct CtxLockstepBackend
 {
 	explicit CtxLockstepBackend(ebo_ctx* ctx) : c(ctx) {}
-	int eval(const double* flows, double* r, double* J, const unsigned char* modes) { return eval_host(c, flows, r, J, modes); }
+	int eval(const double* flows, double* r, double* J, const unsigned char* modes, int windowSlots = 0)
+	{
+		return eval_host(c, flows, r, J, modes, windowSlots);
+	}
 	bool pipelined(int windows, size_t slots) const
 	{
 		return windows >= 16 && slots > env_size("EBO_ZERO_COPY_MAX", 4096) && !std::getenv("EBO_SOLVE_NO_PIPELINE");
@@ -761,13 +864,13 @@ struct CtxLockstepBackend
 			}
 		}
 	}
-	int eval_begin(const double* flows, const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac)
+	int eval_begin(const double* flows, const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, int windowSlots)
 	{
-		return ebo_host::eval_begin(c, flows, modes, g, s0, s1, wantJac, done[g]);
+		return ebo_host::eval_begin(c, flows, modes, g, s0, s1, wantJac, done[g], windowSlots);
 	}
-	int eval_finish(const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, double* r, double* J)
+	int eval_finish(const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, double* r, double* J, int windowSlots)
 	{
-		return ebo_host::eval_finish(c, modes, s0, s1, wantJac, r, J, done[g]);
+		return ebo_host::eval_finish(c, modes, s0, s1, wantJac, r, J, done[g], windowSlots);
 	}
 	ebo_ctx* c;
 	hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -74,6 +74,7 @@ struct ebo_ctx
 	unsigned char* d_modes = nullptr;        // per-flow-slot evaluation modes of a lock-step solve
 	size_t modes_cap = 0;
 	const unsigned char* modes_active = nullptr;  // non-null only inside eval_host(modes)
+	LiveWindows live_active;                      // n > 0 only inside a compact round of a pipelined lock-step solve
 	double2* d_opt_grid = nullptr;   // Optimizer::setGrad's interleaved gradient grid [H][W]
 	bool opt_grid_valid = false;
 	void* d_opt = nullptr;           // scratch of ebo_optimizer_eval / _solve

@@ -74,6 +74,18 @@ struct SolveConsts
 	double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
 };
 
+// The windows of a batch that a launch covers, for lock-step solves whose batch has thinned out (late rounds
+// of EBO_SOLVE_GLOBAL: a few stragglers of 256 windows): workgroups are created for these windows' units
+// only, and the mode of a window (1 value, 2 value + Jacobian) rides in its entry.  Passed BY VALUE as a
+// kernel argument -- no copy, no extra command on the stream; n = 0: the launch covers every unit.
+constexpr int kLiveMax = 64;
+struct LiveWindows
+{
+	int n = 0;
+	int upw = 1;          // units per window (P + 1: the stray unit)
+	int ent[kLiveMax];    // window << 2 | mode
+};
+
 // Per-block partial sums of the variance objective: S1, S2, n, D1[2], D2[2], pad.
 static const int kPartialStride = 8;
 
@@ -100,6 +112,7 @@ struct EvalLaunch
 	double* d_out;         // [n_flow][3]
 	double fd_step;        // > 0: combine as central differences
 	const unsigned char* d_modes = nullptr;  // per flow slot: 0 skip, 1 value, 2 value + Jacobian (impl 3, fused path)
+	LiveWindows live;      // n > 0: only these windows (impl 3, fused path)
 	EvalConsts c;
 };
 int launch_eval_variance(const EvalLaunch& L, void* stream);
@@ -139,6 +152,7 @@ struct EdgeLaunch
 	double* d_out;        // [n_flow][3]
 	const unsigned char* d_modes = nullptr;  // per flow slot: 0 skip, 1 value, 2 value + Jacobian
 	bool for_solve = false;  // the launch is k_solve_edge (picks the workgroup size of its instantiations)
+	LiveWindows live;        // n > 0: only these windows (one flow set)
 	EvalConsts c;
 	EdgeConsts ec;
 };

@@ -2909,10 +2909,15 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		{
 			return -2;
 		}
-		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
+		const bool fusedPath = L.tiles == 1 && L.flow_sets == 1;
+		LiveWindows live = L.live;
+		if (!fusedPath)
+		{
+			live.n = 0;
+		}
+		hipLaunchKernelGGL(kern, live.n > 0 ? dim3(live.n * live.upw) : grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
 						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
-						   L.d_partials, L.d_out, L.c,
-						   (L.tiles == 1 && L.flow_sets == 1) ? L.d_modes : nullptr);
+						   L.d_partials, L.d_out, L.c, fusedPath ? L.d_modes : nullptr, live);
 	}
 	else
 	{
@@ -3430,9 +3435,14 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 	{
 		return -2;
 	}
-	hipLaunchKernelGGL(edgeKern, dim3(L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
+	LiveWindows live = L.live;
+	if (L.flow_sets != 1)
+	{
+		live.n = 0;
+	}
+	hipLaunchKernelGGL(edgeKern, dim3(live.n > 0 ? live.n * live.upw : L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
 					   L.d_events, L.d_units, L.d_flows, L.want_jac, L.cap_px, L.fd_step, L.d_scratch,
-					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec, L.flow_sets == 1 ? L.d_modes : nullptr);
+					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec, L.flow_sets == 1 ? L.d_modes : nullptr, live);
 	if (check_launch())
 	{
 		return -2;

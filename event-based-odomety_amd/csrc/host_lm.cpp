@@ -27,6 +27,79 @@ inline void huber_rho(double a, double s, double& rho0, double& rho1)
 		rho1 = 1.0;
 	}
 }
+
+// pitch of a column of the band: band + 1 entries, then at least three ZEROS that the four-wide loads below
+// may read (and that stay zero: 0 - 0 * l), rounded up to a multiple of four
+inline int band_pitch(int band)
+{
+	return (band + 1 + 3 + 3) & ~3;
+}
+
+// Banded Cholesky A = L L' in place on columns (entry (i, j), j <= i, at A[j * pitch + (i - j)]); false if a
+// pivot is not positive and finite.  With 2 P = 216 unknowns and a band of 25 this is most of an LM step,
+// and the LM steps are what bounds a lock-step round once the windows of a batch have thinned out
+// (DESIGN 4.3).  Every entry is one chain
+//     s = A(i,j) - L(i,k0) L(j,k0) - L(i,k0+1) L(j,k0+1) - ...   (k ascending from i - band),   L(i,j) = s / L(j,j),
+// one rounding per operation (no contraction).  The chains of FOUR consecutive rows of a column advance
+// together in one vector register -- each in its own order, so the factor has the bits of the scalar
+// row-by-row loop this replaces (checked: same trajectories bit for bit); a row whose chain starts later
+// meets the zero padding behind the pivot column's band until then (s - 0 = s).
+typedef double lm_v4d __attribute__((vector_size(32), aligned(8), may_alias));
+__attribute__((always_inline)) inline bool band_cholesky_body(double* A, int n, int band, int pitch)
+{
+	for (int j = 0; j < n; ++j)
+	{
+		double* const Cj = A + static_cast<size_t>(j) * pitch;
+		const int mj = std::min(n - 1, j + band) - j;  // rows of the band below the diagonal
+		for (int c = 0; c <= mj; c += 4)
+		{
+			lm_v4d v = *reinterpret_cast<const lm_v4d*>(Cj + c);
+			for (int k = std::max(0, j + c - band); k < j; ++k)
+			{
+				const double* const Ck = A + static_cast<size_t>(k) * pitch + (j - k);
+				const double ljk = Ck[0];
+				const lm_v4d lk = *reinterpret_cast<const lm_v4d*>(Ck + c);
+				v -= lk * ljk;
+			}
+			*reinterpret_cast<lm_v4d*>(Cj + c) = v;
+		}
+		const double d = Cj[0];
+		if (!(d > 0.0) || !std::isfinite(d))
+		{
+			return false;
+		}
+		const double ljj = std::sqrt(d);
+		Cj[0] = ljj;
+		for (int t = 1; t <= mj; ++t)
+		{
+			Cj[t] = Cj[t] / ljj;
+		}
+		// what the vector stores left behind the band (rows beyond the band or the matrix collect only
+		// 0 - 0 * l = 0, unless l is not finite -- then the pivot test above has already returned)
+	}
+	return true;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) bool band_cholesky_avx2(double* A, int n, int band, int pitch)
+{
+	return band_cholesky_body(A, n, band, pitch);
+}
+#endif
+bool band_cholesky_plain(double* A, int n, int band, int pitch)
+{
+	return band_cholesky_body(A, n, band, pitch);
+}
+inline bool band_cholesky(double* A, int n, int band, int pitch)
+{
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	if (avx2)
+	{
+		return band_cholesky_avx2(A, n, band, pitch);
+	}
+#endif
+	return band_cholesky_plain(A, n, band, pitch);
+}
 }  // namespace
 
 HostLm::HostLm(int npx, int npy, const std::vector<uint8_t>& active, double tvWeight,
@@ -90,7 +163,7 @@ HostLm::HostLm(int npx, int npy, const std::vector<uint8_t>& active, double tvWe
 	scale_.assign(n_, 1.0);
 	diag_.assign(n_, 0.0);
 	step_.assign(n_, 0.0);
-	band_store_.assign(static_cast<size_t>(n_) * (band_ + 1), 0.0);
+	band_store_.assign(static_cast<size_t>(n_) * band_pitch(band_), 0.0);
 	maxNonmono_ = o_.use_nonmonotonic ? o_.max_consecutive_nonmonotonic : 0;
 	radius_ = o_.initial_radius;
 	if (n_ == 0 || rows == 0)
@@ -210,7 +283,7 @@ void HostLm::afterJacobian()
 bool HostLm::computeStep()
 {
 	const size_t nd = dataPatch_.size();
-	const int bw = band_ + 1;
+	const int bw = band_pitch(band_);
 	if (!reuseDiag_)
 	{
 		std::fill(diag_.begin(), diag_.end(), 0.0);
@@ -235,12 +308,12 @@ bool HostLm::computeStep()
 	}
 	reuseDiag_ = true;
 
-	// Lower band of J'J + D'D: entry (i, j), j <= i, at [i*bw + (i-j)].
+	// Lower band of J'J + D'D, column by column: entry (i, j), j <= i, at [j*bw + (i-j)].
 	std::fill(band_store_.begin(), band_store_.end(), 0.0);
 	std::fill(step_.begin(), step_.end(), 0.0);
 	auto addPair = [&](int ca, double va, int cb, double vb) {
 		const int i = std::max(ca, cb), j = std::min(ca, cb);
-		band_store_[static_cast<size_t>(i) * bw + (i - j)] += va * vb;
+		band_store_[static_cast<size_t>(j) * bw + (i - j)] += va * vb;
 	};
 	for (size_t i = 0; i < nd; ++i)
 	{
@@ -271,49 +344,35 @@ bool HostLm::computeStep()
 		const double l = std::sqrt(diag_[c] / radius_);
 		band_store_[static_cast<size_t>(c) * bw] += l * l;
 	}
-	// Banded Cholesky A = L L', in place.
-	for (int j = 0; j < n_; ++j)
+	double* const A = band_store_.data();
+	if (!band_cholesky(A, n_, band_, bw))
 	{
-		double d = band_store_[static_cast<size_t>(j) * bw];
-		for (int k = std::max(0, j - band_); k < j; ++k)
-		{
-			const double l = band_store_[static_cast<size_t>(j) * bw + (j - k)];
-			d -= l * l;
-		}
-		if (!(d > 0.0) || !std::isfinite(d))
-		{
-			return false;
-		}
-		const double ljj = std::sqrt(d);
-		band_store_[static_cast<size_t>(j) * bw] = ljj;
-		for (int i = j + 1; i <= std::min(n_ - 1, j + band_); ++i)
-		{
-			double s = band_store_[static_cast<size_t>(i) * bw + (i - j)];
-			for (int k = std::max(0, i - band_); k < j; ++k)
-			{
-				s -= band_store_[static_cast<size_t>(i) * bw + (i - k)] *
-					 band_store_[static_cast<size_t>(j) * bw + (j - k)];
-			}
-			band_store_[static_cast<size_t>(i) * bw + (i - j)] = s / ljj;
-		}
+		return false;
 	}
-	for (int i = 0; i < n_; ++i)
+	// L y = b by columns (y_k, then its multiples off the rows below: row i again collects its terms in
+	// ascending k), L' x = y by rows of L' = columns of L (a dot product in ascending k, as before)
+	for (int k = 0; k < n_; ++k)
 	{
-		double s = step_[i];
-		for (int k = std::max(0, i - band_); k < i; ++k)
+		const double* __restrict const Ck = A + static_cast<size_t>(k) * bw;
+		const double y = step_[k] / Ck[0];
+		step_[k] = y;
+		const int m = std::min(n_ - 1, k + band_) - k;
+		double* __restrict const sk = step_.data() + k;
+		for (int t = 1; t <= m; ++t)
 		{
-			s -= band_store_[static_cast<size_t>(i) * bw + (i - k)] * step_[k];
+			sk[t] -= Ck[t] * y;
 		}
-		step_[i] = s / band_store_[static_cast<size_t>(i) * bw];
 	}
 	for (int i = n_ - 1; i >= 0; --i)
 	{
-		double s = step_[i];
-		for (int k = i + 1; k <= std::min(n_ - 1, i + band_); ++k)
+		const double* const Ci = A + static_cast<size_t>(i) * bw;
+		double sv = step_[i];
+		const int m = std::min(n_ - 1, i + band_) - i;
+		for (int t = 1; t <= m; ++t)
 		{
-			s -= band_store_[static_cast<size_t>(k) * bw + (k - i)] * step_[k];
+			sv -= Ci[t] * step_[i + t];
 		}
-		step_[i] = s / band_store_[static_cast<size_t>(i) * bw];
+		step_[i] = sv / Ci[0];
 	}
 	for (int c = 0; c < n_; ++c)
 	{

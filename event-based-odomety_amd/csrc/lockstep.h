@@ -10,18 +10,24 @@
 // AddressSanitizer + UBSan by the CPU test-suite (sanitizers on the CPU build).
 //
 // Backend:
-//   int  eval(const double* flows, double* r, double* J /* may be null */, const unsigned char* modes /* may be null */);
-//        synchronous; modes[i]: 0 skip slot i, 1 value, 2 value + Jacobian (null: all slots, Jacobian iff J)
+//   int  eval(const double* flows, double* r, double* J /* may be null */, const unsigned char* modes /* may be null */,
+//             int windowSlots = 0);
+//        synchronous; modes[i]: 0 skip slot i, 1 value, 2 value + Jacobian (null: all slots, Jacobian iff J);
+//        windowSlots > 0: ONE mode per aligned run of that many slots (a window's patches)
 //   bool pipelined(int windows, size_t slots);  int groups();
 //   int  pipeline_begin(size_t slots, int groups);  void pipeline_end(int groups);
-//   int  eval_begin(const double* flows, const unsigned char* modes, int group, size_t s0, size_t s1, bool wantJac);
-//        asynchronous: may read flows[2 s0, 2 s1) and modes[0, slots) only until it returns
-//   int  eval_finish(const unsigned char* modes, int group, size_t s0, size_t s1, bool wantJac, double* r, double* J);
+//   int  eval_begin(const double* flows, const unsigned char* modes, int group, size_t s0, size_t s1, bool wantJac,
+//                   int windowSlots);
+//        asynchronous: may read flows[2 s0, 2 s1) and modes[0, slots) only until it returns; windowSlots > 0: the
+//        caller guarantees ONE mode per aligned run of that many slots (a window's patches)
+//   int  eval_finish(const unsigned char* modes, int group, size_t s0, size_t s1, bool wantJac, double* r, double* J,
+//                    int windowSlots);
 //        waits for that group's round, writes r / J of slots [s0, s1) with a non-zero mode
 #pragma once
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,7 +46,8 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 	// (with spinning workers a thread pays off from two windows' LM steps up: 64 windows, 17.2 -> see DESIGN 4.3)
 	HostPool pool(static_cast<size_t>(Wn), 2);
 	// trace (EBO_SOLVE_TRACE=1): where a lock-step solve spends its time (stderr, one line per call)
-	double tReq = 0.0, tEval = 0.0, tSup = 0.0;
+	double tReq = 0.0, tEval = 0.0, tSup = 0.0, tLaunch = 0.0;
+	const auto tStart = std::chrono::steady_clock::now();
 	int rounds = 0;
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -72,30 +79,53 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 			gmodes[g].assign(nfAll, 0);
 		}
 		bool inflight[kMaxGroups] = {false, false, false, false}, gJac[kMaxGroups] = {false, false, false, false};
-		// request: every window of the half says what it wants next; true if any is still running
+		// the windows of a group that have not finished (a finished window never asks again: its mode stays 0)
+		std::vector<size_t> running[kMaxGroups];
+		for (int g = 0; g < G; ++g)
+		{
+			for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
+			{
+				running[g].push_back(w);
+			}
+		}
+		// request: every running window of the group says what it wants next; true if any is still running
 		auto request = [&](int g) {
+			std::vector<size_t>& run = running[g];
 			// (a request is a copy of 2 P doubles and a memset: threads only from 64 windows per thread up)
-			pool.parallel_for(wSplit[g + 1] - wSplit[g], 64, [&](size_t b, size_t e) {
-				for (size_t w = wSplit[g] + b; w < wSplit[g] + e; ++w)
+			pool.parallel_for(run.size(), 64, [&](size_t b, size_t e) {
+				for (size_t k = b; k < e; ++k)
 				{
+					const size_t w = run[k];
 					const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
 					wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
 					std::memset(&gmodes[g][w * P], wmode[w], static_cast<size_t>(P));
 				}
 			});
-			bool any = false;
 			gJac[g] = false;
-			for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
+			size_t keep = 0;
+			for (size_t k = 0; k < run.size(); ++k)
 			{
-				any = any || wmode[w] != 0;
-				gJac[g] = gJac[g] || wmode[w] == 2;
+				const size_t w = run[k];
+				if (wmode[w] != 0)
+				{
+					gJac[g] = gJac[g] || wmode[w] == 2;
+					run[keep++] = w;
+				}
 			}
-			return any;
+			run.resize(keep);
+			return keep != 0;
 		};
 		auto launch = [&](int g) {
 			inflight[g] = true;
 			++rounds;
-			return be.eval_begin(flows.data(), gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g]);
+			const auto tl = now();
+			struct Acc
+			{
+				double& t;
+				std::chrono::steady_clock::time_point t0;
+				~Acc() { t += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+			} acc{tLaunch, tl};
+			return be.eval_begin(flows.data(), gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g], P);
 		};
 		for (int g = 0; g < G && rc == EBO_OK; ++g)
 		{
@@ -116,23 +146,16 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 					continue;
 				}
 				const auto t1 = now();
-				rc = be.eval_finish(gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g], r.data(), J.data());
+				rc = be.eval_finish(gmodes[g].data(), g, wSplit[g] * P, wSplit[g + 1] * P, gJac[g], r.data(), J.data(), P);
 				inflight[g] = false;
 				if (rc)
 				{
 					break;
 				}
 				const auto t2 = now();
-				// the windows of the half that are still running (late in a solve: a few stragglers, which
+				// the windows of the group that are still running (late in a solve: a few stragglers, which
 				// then do not pay for waking the pool)
-				live.clear();
-				for (size_t w = wSplit[g]; w < wSplit[g + 1]; ++w)
-				{
-					if (wmode[w] != 0)
-					{
-						live.push_back(w);
-					}
-				}
+				live = running[g];
 				pool.parallel_for(live.size(), 2, [&](size_t b, size_t e) {
 					for (size_t k = b; k < e; ++k)
 					{
@@ -144,7 +167,13 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 				const bool more = request(g);
 				tEval += ms(t1, t2);
 				tSup += ms(t2, t3);
-				tReq += ms(t3, now());
+				const auto t4 = now();
+				tReq += ms(t3, t4);
+				if (trace && std::getenv("EBO_SOLVE_TRACE_ROUNDS"))
+				{
+					std::fprintf(stderr, "[ebo]   round %4d group %d live %4zu jac %d: wait %.3f supply %.3f request %.3f ms\n", rounds, g,
+								 live.size(), gJac[g] ? 1 : 0, ms(t1, t2), ms(t2, t3), ms(t3, t4));
+				}
 				if (more)
 				{
 					rc = launch(g);
@@ -184,7 +213,7 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 		}
 		// all windows in the same phase (always so for a single window): no mode table needed
 		const auto t1 = now();
-		int rc = be.eval(flows.data(), r.data(), anyJac ? J.data() : nullptr, uniform ? nullptr : modes.data());
+		int rc = be.eval(flows.data(), r.data(), anyJac ? J.data() : nullptr, uniform ? nullptr : modes.data(), P);
 		if (rc)
 		{
 			return rc;
@@ -207,8 +236,8 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 	}
 	if (trace)
 	{
-		std::fprintf(stderr, "[ebo] lock-step solve: %d windows, %d rounds: request %.2f ms, evaluation (staging + kernels + sync; pipelined: waiting only) %.2f ms, supply (LM steps) %.2f ms\n",
-					 Wn, rounds, tReq, tEval, tSup);
+		std::fprintf(stderr, "[ebo] lock-step solve: %d windows, %d rounds: request %.2f ms, evaluation (staging + kernels + sync; pipelined: waiting only) %.2f ms, supply (LM steps) %.2f ms, launches (pipelined) %.2f ms, driver total %.2f ms\n",
+					 Wn, rounds, tReq, tEval, tSup, tLaunch, ms(tStart, now()));
 	}
 	return 0;
 }

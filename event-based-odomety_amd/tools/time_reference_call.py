@@ -1,6 +1,7 @@
 """Times the reference-default configuration (240x180, 20x20 patches, 15 k events per window,
 edge loss, TV-coupled global LM: FeatureDetector::compensateEventsContrast as shipped) for
 1..N independent windows advanced in lock step.  usage: time_reference_call.py [LOSS] [WINDOWS ...]"""
+import hashlib
 import importlib
 import os
 import sys
@@ -30,8 +31,9 @@ def main():
             s = ss[0]
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        print("loss %d, %4d windows: %.2f ms total, %.3f ms per window, %d iterations, %d + %d evaluations per data term"
-              % (loss, n, best * 1e3, best * 1e3 / n, s.iterations, s.num_evals_cost, s.num_evals_jac), flush=True)
+        print("loss %d, %4d windows: %.2f ms total, %.3f ms per window, %d iterations, %d + %d evaluations per data term, flows md5 %s"
+              % (loss, n, best * 1e3, best * 1e3 / n, s.iterations, s.num_evals_cost, s.num_evals_jac,
+                 hashlib.md5(np.ascontiguousarray(flows).tobytes()).hexdigest()[:12]), flush=True)
         c.close()
 
 

@@ -78,7 +78,7 @@ struct CpuBackend
 			J[1] = e * d1;
 		}
 	}
-	int eval(const double* flows, double* r, double* J, const unsigned char* modes)
+	int eval(const double* flows, double* r, double* J, const unsigned char* modes, int = 0)
 	{
 		for (size_t i = 0; i < n; ++i)
 		{
@@ -119,7 +119,7 @@ struct CpuBackend
 		}
 	}
 	// like the device: the inputs are copied before the call returns, the work happens elsewhere
-	int eval_begin(const double* flows, const unsigned char* modes, int g, size_t s0, size_t s1, bool)
+	int eval_begin(const double* flows, const unsigned char* modes, int g, size_t s0, size_t s1, bool, int)
 	{
 		std::memcpy(&stageFlows[g][2 * s0], flows + 2 * s0, (s1 - s0) * 2 * sizeof(double));
 		std::memcpy(stageModes[g].data(), modes, n);
@@ -136,7 +136,7 @@ struct CpuBackend
 		++evals;
 		return 0;
 	}
-	int eval_finish(const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, double* r, double* J)
+	int eval_finish(const unsigned char* modes, int g, size_t s0, size_t s1, bool wantJac, double* r, double* J, int)
 	{
 		workers[g].join();
 		for (size_t i = s0; i < s1; ++i)
