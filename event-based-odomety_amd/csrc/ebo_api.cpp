@@ -588,7 +588,7 @@ int ensure_device_modes(ebo_ctx* c, size_t nf)
 // windows, the caller vouches for one mode per window (windowSlots == P) and at most kLiveMax are running.
 bool live_windows_of(const ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, int windowSlots, LiveWindows& live)
 {
-	static const bool noCompact = std::getenv("EBO_SOLVE_NO_COMPACT") != nullptr;
+	const bool noCompact = std::getenv("EBO_SOLVE_NO_COMPACT") != nullptr;  // (A/B and tests: read per round)
 	live.n = 0;
 	if (c->custom_n || c->P <= 0 || windowSlots != c->P || s0 % c->P != 0 || s1 % c->P != 0 || noCompact)
 	{

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace ebo
@@ -92,7 +93,7 @@ bool band_cholesky_plain(double* A, int n, int band, int pitch)
 inline bool band_cholesky(double* A, int n, int band, int pitch)
 {
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-	static const bool avx2 = __builtin_cpu_supports("avx2");
+	static const bool avx2 = __builtin_cpu_supports("avx2") && !std::getenv("EBO_LM_NO_AVX2");  // (the knob: tests run both)
 	if (avx2)
 	{
 		return band_cholesky_avx2(A, n, band, pitch);

@@ -443,6 +443,34 @@ def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
     assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", ["variance", "edge"])
+@pytest.mark.parametrize("n", [6, 41])
+def test_thinned_out_rounds_as_window_lists_keep_the_bits(ebo, synth, monkeypatch, loss, n):
+    """Late in a lock-step solve few windows of a batch are still running; a round then launches workgroups for
+    those windows' units only (a list in the kernel arguments, flows and results through pinned memory) instead
+    of every unit with a mode table and copies.  Same evaluations of the same points: flows, iteration counts and
+    final costs equal the list-free path bit for bit, in the plain (6 windows) and the pipelined (41) driver."""
+    ev, offsets, _ = synth.make_stream(0, n)
+    kw = dict(image_w=240, image_h=180, patch_w=20, patch_h=20,
+              loss=ebo.LOSS_VARIANCE if loss == "variance" else ebo.LOSS_EDGE, max_events=len(ev), max_windows=n)
+    out = []
+    for no_lists in (False, True):
+        if no_lists:
+            monkeypatch.setenv("EBO_SOLVE_NO_COMPACT", "1")
+        else:
+            monkeypatch.delenv("EBO_SOLVE_NO_COMPACT", raising=False)
+        with ebo.Context(**kw) as c:
+            c.set_windows(ev, offsets)
+            opts = ebo.default_solver()
+            opts.max_num_iterations = 15
+            flows, summ = c.solve(opts)
+            out.append((flows.copy(), [(s.iterations, s.final_cost, s.termination, s.num_evals_cost, s.num_evals_jac) for s in summ]))
+    monkeypatch.delenv("EBO_SOLVE_NO_COMPACT", raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert len({s[0] for s in out[0][1]}) > 1  # the windows do not all stop together: some rounds were thinned out
+
+
 def test_pipelined_lock_step_solve_equals_the_plain_one(ebo, synth, monkeypatch):
     """With 16 or more windows the TV-coupled host LM runs two halves in flight (one half's LM steps
     on the host while the device evaluates the other): per window the same requests in the same
