@@ -472,7 +472,7 @@ def test_thinned_out_rounds_as_window_lists_keep_the_bits(ebo, synth, monkeypatc
 
 
 def test_pipelined_lock_step_solve_equals_the_plain_one(ebo, synth, monkeypatch):
-    """With 16 or more windows the TV-coupled host LM runs two halves in flight (one half's LM steps
+    """With four or more windows the TV-coupled host LM runs two halves in flight (one half's LM steps
     on the host while the device evaluates the other): per window the same requests in the same
     order, so the same bits as the one-round-at-a-time loop; and the same answer as a window alone."""
     n = 21
