@@ -904,16 +904,16 @@ template <int FIXED>
 __device__ __forceinline__ void eval_unit(const uint64_t* __restrict__ ev, const Unit& u,
 										   double m0, double m1, bool wantJac, int capDoubles,
 										   const EvalConsts& c, double* lds, double& r, double& j0,
-										   double& j1)
+										   double& j1, EvalReuse* ru = nullptr)
 {
 	double S[7];
 	if (FIXED == 3)
 	{
-		eval_unit3<true>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+		eval_unit3<true>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S, ru);
 	}
 	else if (FIXED == 4)
 	{
-		eval_unit3<false>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S);
+		eval_unit3<false>(ev, u, m0, m1, wantJac, 0, 1, capDoubles, c, lds, S, ru);
 	}
 	else
 	{
@@ -1199,7 +1199,7 @@ template <int FIXED>
 __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __restrict__ events,
 									const Unit* __restrict__ units, int capDoubles,
 									double* __restrict__ flowsOut, int32_t* __restrict__ stats,
-									EvalConsts c, SolveConsts o)
+									EvalConsts c, SolveConsts o, int noReuse)
 {
 	extern __shared__ double lds[];
 	const Unit u = units[blockIdx.x];
@@ -1215,9 +1215,17 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 		// vector instructions, replicated in every lane ~100 VGPRs live across the objective.
 		static_assert(sizeof(LmUnit) <= 64 * sizeof(double), "LmUnit must fit red[64..127]");
 		LmUnit& lm = *reinterpret_cast<LmUnit*>(lds + 64);
+		// the record of the image in LDS (ebo_eval3.inc, EvalReuse): doubles 148..157 of the header, behind the 32
+		// ints the bounding-box reduction uses (at most eight waves)
+		EvalReuse* ru = (FIXED >= 3 && !noReuse) ? reinterpret_cast<EvalReuse*>(lds + kRedDoubles + 20) : nullptr;
+		static_assert(sizeof(EvalReuse) <= (kLdsHeader - kRedDoubles - 20) * sizeof(double), "EvalReuse must fit the header");
 		if (threadIdx.x == 0)
 		{
 			lm.begin();
+			if (ru)
+			{
+				ru->valid = 0.0;
+			}
 		}
 		for (;;)
 		{
@@ -1229,7 +1237,7 @@ __global__ void __launch_bounds__(512) k_solve_independent(const uint64_t* __res
 			const double q0 = lm.q0, q1 = lm.q1;
 			const bool qJac = lm.qJac;
 			double r, a, b;
-			eval_unit<FIXED>(ev, u, q0, q1, qJac, capDoubles, c, lds, r, a, b);
+			eval_unit<FIXED>(ev, u, q0, q1, qJac, capDoubles, c, lds, r, a, b, ru);
 			if (threadIdx.x == 0)
 			{
 				lm.more = lm.advance(r, a, b, o) ? 1 : 0;
@@ -3509,7 +3517,7 @@ int launch_solve_independent(const SolveLaunch& L, void* stream)
 		return -2;
 	}
 	hipLaunchKernelGGL(kern, dim3(L.n_units), dim3(L.block), L.lds_bytes, s, L.d_events,
-					   L.d_units, L.cap_doubles, L.d_flows_out, L.d_stats, L.c, L.s);
+					   L.d_units, L.cap_doubles, L.d_flows_out, L.d_stats, L.c, L.s, std::getenv("EBO_SOLVE_NO_REUSE") ? 1 : 0);
 	return check_launch();
 }
 

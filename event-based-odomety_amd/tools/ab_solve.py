@@ -11,7 +11,7 @@ cfg = synth.CONFIGS[config]
 ev, offsets, gt = synth.make_stream(config, windows)
 ref = None
 for st in sys.argv[3:] or [""]:
-    for k in ("EBO_SOLVE_BLOCK", "EBO_LDS_KB"):
+    for k in ("EBO_SOLVE_BLOCK", "EBO_LDS_KB", "EBO_SOLVE_NO_REUSE"):
         os.environ.pop(k, None)
     for kv in filter(None, st.split(",")):
         k, v = kv.split("="); os.environ[k] = v
