@@ -3483,7 +3483,7 @@ int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows
 		return -2;
 	}
 	hipLaunchKernelGGL(kern, dim3(L.n_units), dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units, L.cap_px,
-					   L.d_scratch, L.scratch_stride, d_flows_out, d_stats, L.c, L.ec, o);
+					   L.d_scratch, L.scratch_stride, d_flows_out, d_stats, L.c, L.ec, o, std::getenv("EBO_SOLVE_NO_REUSE") ? 1 : 0);
 	return check_launch();
 }
 

@@ -1,0 +1,29 @@
+"""A/B on the GPU box: the device-resident edge solve (k_solve_edge) with and without the forward-pass reuse
+(EBO_SOLVE_NO_REUSE=1); the flows must be bit-identical.  usage: edge_reuse.py <config> <windows>"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+ebo = importlib.import_module("event-based-odomety_amd")
+synth = importlib.import_module("event-based-odomety_amd.synth")
+config, windows = int(sys.argv[1]), int(sys.argv[2])
+cfg = synth.CONFIGS[config]
+ev, offsets, gt = synth.make_stream(config, windows)
+ref = None
+for st in ("", "EBO_SOLVE_NO_REUSE=1"):
+    os.environ.pop("EBO_SOLVE_NO_REUSE", None)
+    for kv in filter(None, st.split(",")):
+        k, v = kv.split("="); os.environ[k] = v
+    with ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0], patch_h=cfg["patch"][1],
+                     loss=ebo.LOSS_EDGE, tv_weight=0.0, max_events=len(ev), max_windows=windows) as c:
+        c.set_windows(ev, offsets)
+        c.solve(mode=ebo.SOLVE_INDEPENDENT)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            flows, s = c.solve(mode=ebo.SOLVE_INDEPENDENT)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    ref = flows if ref is None else ref
+    print("edge solve cfg %d win %d [%-22s] %8.3f ms  bit-identical to first: %s  (window 0: %d iterations, %d + %d evaluations)"
+          % (config, windows, st, best * 1e3, np.array_equal(flows, ref), s[0].iterations, s[0].num_evals_cost, s[0].num_evals_jac), flush=True)
