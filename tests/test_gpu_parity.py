@@ -443,6 +443,35 @@ def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
     assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
 
 
+@pytest.mark.parametrize("loss", ["variance", "edge"])
+@pytest.mark.parametrize("config", [0, 2])
+def test_device_solve_reusing_the_image_of_an_accepted_step_keeps_the_bits(ebo, synth, monkeypatch, loss, config):
+    """The device-resident per-patch solve evaluates the cost at a candidate and, on acceptance, value and Jacobian
+    at the same point; the second evaluation starts from what the first left in LDS (variance loss: the image, gather
+    pass only; edge loss: image, eigenvalues and directions, from the window maxima on).  Same operations on the
+    same operands: flows, iteration and evaluation counts, terminations equal the full evaluations' bit for bit."""
+    n = 6 if config == 0 else 3
+    ev, offsets, _ = synth.make_stream(config, n)
+    cfg = synth.CONFIGS[config]
+    kw = dict(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0], patch_h=cfg["patch"][1],
+              loss=ebo.LOSS_VARIANCE if loss == "variance" else ebo.LOSS_EDGE, tv_weight=0.0, max_events=len(ev), max_windows=n)
+    out = []
+    for no_reuse in (False, True):
+        if no_reuse:
+            monkeypatch.setenv("EBO_SOLVE_NO_REUSE", "1")
+        else:
+            monkeypatch.delenv("EBO_SOLVE_NO_REUSE", raising=False)
+        with ebo.Context(**kw) as c:
+            c.set_windows(ev, offsets)
+            opts = ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT)
+            opts.max_num_iterations = 12
+            flows, summ = c.solve(opts)
+            out.append((flows.copy(), [(s.iterations, s.termination, s.num_evals_cost, s.num_evals_jac) for s in summ]))
+    monkeypatch.delenv("EBO_SOLVE_NO_REUSE", raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert max(s[3] for s in out[0][1]) > 1  # Jacobian evaluations beyond the first: accepted steps, i.e. reuse happened
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("loss", ["variance", "edge"])
 @pytest.mark.parametrize("n", [6, 41])
