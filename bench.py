@@ -554,6 +554,9 @@ def main():
                   "windows_in_batch": wt, "grid_rows_per_gpu": S["rows"], "patches_per_gpu_per_step": S["n_units"],
                   "events_per_gpu_per_step": S["n_events"], "event_evaluations_per_gpu_per_step": units_per_step,
                   "loss": "variance", "grad": "jet",
+                  "event_evaluations": "events x the solver's evaluation requests (cost + Jacobian, from its statistics); a Jacobian "
+                                       "request at the point whose cost was just evaluated runs the gather pass on the image that "
+                                       "evaluation left in LDS (bit-identical result; EBO_SOLVE_NO_REUSE=1 rebuilds the image)",
                   "step": "device-resident per-patch solve of the shard (ebo_solve_device) + one all-gather of the solved flows"
                           + ("" if args.no_c4_image else " + partial final count image of the shard's events (ebo_count_image_shard)"
                              " + one reduce of the images onto rank 0"),
@@ -623,9 +626,17 @@ def main():
         st = d_stats.cpu().numpy().reshape(Wn, P, 4)
         ne = np.array([[ctx.patch_info(p, w)[0] for p in range(P)] for w in range(Wn)])
         evals = (st[:, :, 1] + st[:, :, 2]) * ne
+        os.environ["EBO_SOLVE_NO_REUSE"] = "1"  # every evaluation rebuilds its image (the solve of rounds 1-2)
+        ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
+        solve_ms_full = timed(lambda: ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr()), 2)
+        os.environ.pop("EBO_SOLVE_NO_REUSE")
         extras["solve_independent"] = {
             "ms": solve_ms, "windows": Wn, "mevents_per_s": rate(float(evals.sum()), solve_ms),
-            "mean_evals_per_patch": float((st[:, :, 1] + st[:, :, 2])[st[:, :, 2] > 0].mean())}
+            "mean_evals_per_patch": float((st[:, :, 1] + st[:, :, 2])[st[:, :, 2] > 0].mean()),
+            "mean_jacobian_evals_per_patch": float(st[:, :, 2][st[:, :, 2] > 0].mean()),
+            "ms_every_evaluation_rebuilding_its_image": solve_ms_full,
+            "note": "evaluations = the solver's requests; a Jacobian request at the point whose cost was just evaluated "
+                    "reuses the image in LDS (same bits)"}
         # single-window latency (one window, one launch)
         c1 = ebo.Context(device=dev, image_w=cfg["image"][0], image_h=cfg["image"][1],
                          patch_w=cfg["patch"][0], patch_h=cfg["patch"][1], loss=ebo.LOSS_VARIANCE,
