@@ -45,6 +45,42 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 	std::vector<unsigned char> modes(static_cast<size_t>(Wn) * P, 0), wmode(Wn, 0);
 	// (with spinning workers a thread pays off from two windows' LM steps up: 64 windows, 17.2 -> see DESIGN 4.3)
 	HostPool pool(static_cast<size_t>(Wn), 2);
+	// Speculation, once a batch has thinned out and the device waits for the host more than the host for the device: a
+	// window that asks for the COST at a candidate is evaluated with its Jacobian as well; if the step is accepted --
+	// the solver then asks for value and Jacobian at that very point -- the request is answered from that evaluation
+	// without another round trip.  The solver sees the same numbers in the same order (same kernel, same point):
+	// same trajectory, same evaluation counts, fewer rounds.  Applied to rounds of at most specMax running windows
+	// (EBO_SOLVE_SPECULATE, default 8; 0 = never).
+	const char* specEnv = std::getenv("EBO_SOLVE_SPECULATE");
+	const size_t specMax = specEnv ? static_cast<size_t>(std::max(0, std::atoi(specEnv))) : 8;
+	std::vector<unsigned char> spec(static_cast<size_t>(Wn), 0);
+	std::vector<double> specPoint(specMax ? static_cast<size_t>(Wn) * P * 2 : 0);
+	// what window w wants evaluated next, as the mode of the launch: 0 nothing (done), 1 value, 2 value + Jacobian
+	auto ask = [&](size_t w, bool speculate) -> unsigned char {
+		double* fw = &flows[w * P * 2];
+		HostLm::Request q = lm[w].request(fw);
+		if (q == HostLm::NEED_JACOBIAN && spec[w] && std::memcmp(fw, &specPoint[w * P * 2], static_cast<size_t>(P) * 2 * sizeof(double)) == 0)
+		{
+			lm[w].supply(&r[w * P], &J[w * P * 2]);  // the window's slots still hold that evaluation
+			q = lm[w].request(fw);
+		}
+		spec[w] = 0;
+		if (q == HostLm::DONE)
+		{
+			return 0;
+		}
+		if (q == HostLm::NEED_JACOBIAN)
+		{
+			return 2;
+		}
+		if (speculate)
+		{
+			spec[w] = 1;
+			std::memcpy(&specPoint[w * P * 2], fw, static_cast<size_t>(P) * 2 * sizeof(double));
+			return 2;
+		}
+		return 1;
+	};
 	// trace (EBO_SOLVE_TRACE=1): where a lock-step solve spends its time (stderr, one line per call)
 	double tReq = 0.0, tEval = 0.0, tSup = 0.0, tLaunch = 0.0;
 	const auto tStart = std::chrono::steady_clock::now();
@@ -91,13 +127,13 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 		// request: every running window of the group says what it wants next; true if any is still running
 		auto request = [&](int g) {
 			std::vector<size_t>& run = running[g];
+			const bool speculate = specMax != 0 && run.size() <= specMax;
 			// (a request is a copy of 2 P doubles and a memset: threads only from 64 windows per thread up)
 			pool.parallel_for(run.size(), 64, [&](size_t b, size_t e) {
 				for (size_t k = b; k < e; ++k)
 				{
 					const size_t w = run[k];
-					const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
-					wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+					wmode[w] = ask(w, speculate);
 					std::memset(&gmodes[g][w * P], wmode[w], static_cast<size_t>(P));
 				}
 			});
@@ -192,11 +228,20 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 		const auto t0 = now();
 		// every window says what it wants next (its own point, value or value + Jacobian);
 		// finished windows drop out of the launch
+		size_t runningNow = 0;
+		for (int w = 0; w < Wn; ++w)
+		{
+			runningNow += (rounds == 0 || wmode[w] != 0) ? 1 : 0;
+		}
+		const bool speculate = specMax != 0 && runningNow <= specMax;
 		pool.parallel_for(static_cast<size_t>(Wn), 8, [&](size_t b, size_t e) {
 			for (size_t w = b; w < e; ++w)
 			{
-				const HostLm::Request q = lm[w].request(&flows[w * P * 2]);
-				wmode[w] = q == HostLm::DONE ? 0 : (q == HostLm::NEED_JACOBIAN ? 2 : 1);
+				if (rounds != 0 && wmode[w] == 0)
+				{
+					continue;  // finished in an earlier round (its mode table entries are 0 already)
+				}
+				wmode[w] = ask(w, speculate);
 				std::memset(&modes[w * P], wmode[w], static_cast<size_t>(P));
 			}
 		});

@@ -444,6 +444,34 @@ def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
 
 
 @pytest.mark.parametrize("loss", ["variance", "edge"])
+@pytest.mark.parametrize("n", [1, 5, 19])
+def test_speculative_jacobians_in_lock_step_keep_the_bits(ebo, synth, monkeypatch, loss, n):
+    """Once few windows are running, a window that asks for the cost at a candidate is evaluated with its Jacobian
+    as well, and the solver's next request -- value and Jacobian at that very point, if it accepts the step -- is
+    answered from that evaluation without another round.  The solver sees the same numbers in the same order: flows,
+    iteration and evaluation counts, final costs equal the unspeculative solve's bit for bit (one window: the plain
+    driver; 5 and 19: two groups in flight)."""
+    ev, offsets, _ = synth.make_stream(0, n)
+    kw = dict(image_w=240, image_h=180, patch_w=20, patch_h=20,
+              loss=ebo.LOSS_VARIANCE if loss == "variance" else ebo.LOSS_EDGE, max_events=len(ev), max_windows=n)
+    out = []
+    for spec in ("0", None):
+        if spec is None:
+            monkeypatch.delenv("EBO_SOLVE_SPECULATE", raising=False)
+        else:
+            monkeypatch.setenv("EBO_SOLVE_SPECULATE", spec)
+        with ebo.Context(**kw) as c:
+            c.set_windows(ev, offsets)
+            opts = ebo.default_solver()
+            opts.max_num_iterations = 15
+            flows, summ = c.solve(opts)
+            out.append((flows.copy(), [(s.iterations, s.final_cost, s.termination, s.num_evals_cost, s.num_evals_jac) for s in summ]))
+    monkeypatch.delenv("EBO_SOLVE_SPECULATE", raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert max(s[4] for s in out[0][1]) > 1  # accepted steps happened: Jacobian requests beyond the first
+
+
+@pytest.mark.parametrize("loss", ["variance", "edge"])
 @pytest.mark.parametrize("config", [0, 2])
 def test_device_solve_reusing_the_image_of_an_accepted_step_keeps_the_bits(ebo, synth, monkeypatch, loss, config):
     """The device-resident per-patch solve evaluates the cost at a candidate and, on acceptance, value and Jacobian
