@@ -258,17 +258,25 @@ class Comm:
             return out
         return exchange.allgather_rows(t_local, counts, out=out)
 
-    def reduce_sum_to_rank0(self, t_dev):
-        """ONE reduce (sum) of a device tensor onto rank 0, in place there."""
+    def reduce_sum_to_rank0(self, t_dev, staging=None):
+        """ONE reduce (sum) of a device tensor onto rank 0, in place there.  staging: an int32 device tensor of
+        the same shape -- for integer-valued data (event counts, far below 2^31) the collective then moves half the
+        bytes of the f64 image and is exact all the same."""
         if not self.active:
             return t_dev
+        src = t_dev
+        if staging is not None:
+            staging.copy_(t_dev)  # f64 -> int32, exact on counts
+            src = staging
         if self.backend == "gloo":
-            h = t_dev.cpu()
+            h = src.cpu()
             self.dist.reduce(h, dst=0, op=self.dist.ReduceOp.SUM)
             if self.rank == 0:
                 t_dev.copy_(h)
             return t_dev
-        self.dist.reduce(t_dev, dst=0, op=self.dist.ReduceOp.SUM)
+        self.dist.reduce(src, dst=0, op=self.dist.ReduceOp.SUM)
+        if staging is not None and self.rank == 0:
+            t_dev.copy_(staging)
         return t_dev
 
     def allgather_tracks(self, exchange, local):
@@ -305,7 +313,8 @@ def main():
     ap.add_argument("--workload", choices=("auto", "eval", "c4", "replicas"), default="auto")
     ap.add_argument("--config", type=int, default=3, help="eval / replicas: BASELINE config index (3 = configs[2])")
     ap.add_argument("--windows", type=int, default=None, help="eval / replicas: independent windows per GPU per step")
-    ap.add_argument("--c4-windows", type=int, default=4, help="c4: windows in flight PER GPU (batch = N x this)")
+    ap.add_argument("--c4-windows", type=int, default=8, help="c4: windows in flight PER GPU (batch = N x this); "
+                    "8 since round 3: one GPU's shard solves 4 / 8 / 16 / 32 windows in 1.89 / 1.60 / 1.48 / 1.46 ms per window")
     ap.add_argument("--strong", action="store_true", help="c4: keep the batch at --c4-windows windows in total")
     ap.add_argument("--no-c4-image", action="store_true", help="c4: stop the step at solve + all-gather (no final count image)")
     ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
@@ -451,8 +460,10 @@ def main():
         # the final image: flows of ALL patches in patch order [window][P][2], partial image [window][H][W]
         d_grid = torch.zeros((windows_total, npx * npy, 2), dtype=torch.float64, device="cuda")
         d_img = torch.zeros((windows_total, ih, iw), dtype=torch.float64, device="cuda") if not args.no_c4_image else None
+        # the reduce of the partial images moves them as int32 (integer-valued counts): half the bytes, exact
+        d_img32 = torch.zeros((windows_total, ih, iw), dtype=torch.int32, device="cuda") if (d_img is not None and n_ranks > 1) else None
         return dict(cfg=cfg, ctx=ctx, d_sol=d_sol, d_stats=d_stats, d_all=d_all, counts=counts, rows=rows,
-                    t_ref=np.array(t_ref, dtype=np.int64), d_grid=d_grid, d_img=d_img,
+                    t_ref=np.array(t_ref, dtype=np.int64), d_grid=d_grid, d_img=d_img, d_img32=d_img32,
                     n_units=n_units, n_ev_unit=n_ev_unit, n_events=len(ev), npx=npx, npy=npy,
                     windows_total=windows_total, opts=ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
 
@@ -472,7 +483,7 @@ def main():
             at += cnt_q
             col += nq
         S_["ctx"].count_image_shard_device(S_["windows_total"], S_["t_ref"], S_["d_grid"].data_ptr(), S_["d_img"].data_ptr())
-        comm.reduce_sum_to_rank0(S_["d_img"])
+        comm.reduce_sum_to_rank0(S_["d_img"], S_.get("d_img32"))
 
     extras = {}
     roof_kernel = None
@@ -562,7 +573,7 @@ def main():
                              " + one reduce of the images onto rank 0"),
                   "parallelism": "patch rows of every window sharded over %d GPU(s), %s all-gather of flows (16 B/patch)%s per step"
                                  % (world, "RCCL" if comm.backend == "nccl" else (comm.backend or "no"),
-                                    "" if args.no_c4_image else " and reduce of the %d x %d f64 images" % (cfg["image"][0], cfg["image"][1]))}
+                                    "" if args.no_c4_image else " and reduce of the %d x %d count images (moved as int32: exact, half the bytes of f64)" % (cfg["image"][0], cfg["image"][1]))}
 
     # ---- the timed region: W warm-up steps, barrier, EXACTLY K steps, barrier -----------------
     for _ in range(args.warmup):
