@@ -3257,7 +3257,8 @@ int launch_optimizer_solve(const OptLaunch& L, void* stream)
 		block = std::min(std::max((std::atoi(v) / 64) * 64, 64), 256);
 	}
 	hipLaunchKernelGGL(k_optimizer_solve, dim3(L.n_patches), dim3(block), lds, static_cast<hipStream_t>(stream),
-					   L.d_grid, L.img_w, L.img_h, L.d_patches, L.d_nabla, L.d_x, L.d_stats, L.huber, L.s);
+					   L.d_grid, L.img_w, L.img_h, L.d_patches, L.d_nabla, L.d_x, L.d_stats, L.huber, L.s,
+					   std::getenv("EBO_OPT_NO_SPECULATE") ? 0 : 1);
 	return check_launch();
 }
 

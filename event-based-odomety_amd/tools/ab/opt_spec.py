@@ -1,0 +1,47 @@
+"""A/B on the GPU box: the tracker solve (k_optimizer_solve) with and without the speculative linearisation
+(EBO_OPT_NO_SPECULATE=1); poses, flow directions and statistics must be bit-identical.
+usage: opt_spec.py [N_PATCHES ...]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "event-based-odomety_amd", "tools"))
+ebo = importlib.import_module("event-based-odomety_amd")
+from time_optimizer import scene  # noqa: E402
+
+counts = [int(a) for a in sys.argv[1:]] or [1, 100, 1000]
+w, h = 240, 180
+gx, gy = scene(w, h, 1)
+p = ebo.default_params()
+p.image_w, p.image_h = w, h
+c = ebo.Context(p)
+c.optimizer_set_grad(gx, gy)
+rng = np.random.default_rng(2)
+for n in counts:
+    rects = np.stack([rng.uniform(5, w - 30, n), rng.uniform(5, h - 30, n), np.full(n, 25.0), np.full(n, 25.0)], 1)
+    nablas = [rng.integers(-3, 4, (25, 25)).astype(np.float64) for _ in range(n)]
+    poses = np.tile([1.0, 0.0, 0.0, 0.0], (n, 1))
+    fds = rng.uniform(0, 6.28, n)
+    ref = None
+    for st in ("", "EBO_OPT_NO_SPECULATE=1"):
+        os.environ.pop("EBO_OPT_NO_SPECULATE", None)
+        if st:
+            os.environ["EBO_OPT_NO_SPECULATE"] = "1"
+        best = None
+        for _ in range(7):
+            t0 = time.perf_counter()
+            po, fo, sums = c.optimizer_solve(rects, nablas, poses, fds, normalize=True)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out = (np.asarray(po).copy(), np.asarray(fo).copy(),
+               [(s.iterations, s.num_evals_cost, s.num_evals_jac, s.termination, s.final_cost) for s in sums])
+        ref = out if ref is None else ref
+        same = np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and out[2] == ref[2]
+        print("%5d patches [%-22s] solve %.3f ms  bit-identical to first: %s  (%d + %d evaluations)"
+              % (n, st, best * 1e3, same, sum(s[1] for s in out[2]), sum(s[2] for s in out[2])), flush=True)
+c.close()

@@ -286,6 +286,35 @@ def test_device_solve_matches_oracle(ebo, orc, iters):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("iters", [10, 40])
+def test_speculative_linearisation_keeps_the_bits(ebo, orc, monkeypatch, iters):
+    """The tracker solve evaluates a candidate's cost together with the Jacobian sums of that point (one pass over
+    the pixels) and skips the linearisation of an accepted step; the candidate's cost is the double path's.  Poses,
+    flow directions, iteration and evaluation counts, final costs: bit for bit those of the two-pass loop."""
+    grad, items = _batch(orc, 24)
+    opts_d = ebo.optimizer_default_solver(max_num_iterations=iters)
+    out = []
+    for no_spec in (False, True):
+        if no_spec:
+            monkeypatch.setenv("EBO_OPT_NO_SPECULATE", "1")
+        else:
+            monkeypatch.delenv("EBO_OPT_NO_SPECULATE", raising=False)
+        c = _ctx(ebo)
+        try:
+            c.optimizer_set_grad(grad[..., 0], grad[..., 1])
+            poses, fds, sums = c.optimizer_solve([it["rect"] for it in items], [it["raw"] for it in items],
+                                                 [it["start"][0] for it in items], [it["start"][1] for it in items],
+                                                 normalize=True, opts=opts_d)
+        finally:
+            c.close()
+        out.append((np.asarray(poses).copy(), np.asarray(fds).copy(),
+                    [(s.iterations, s.termination, s.num_evals_cost, s.num_evals_jac, s.final_cost) for s in sums]))
+    monkeypatch.delenv("EBO_OPT_NO_SPECULATE", raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    assert max(s[3] for s in out[0][2]) > 1  # accepted steps happened
+
+
+@pytest.mark.gpu
 def test_device_solve_edge_cases(ebo, orc):
     grad, items = _batch(orc, 3)
     c = _ctx(ebo)
