@@ -174,6 +174,42 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
 	}
 }
 
+// Up to 16 values per thread in ONE pass (two barriers) for workgroups of at most eight waves: the same wave
+// reduction and the same order over the waves per value as block_sum, so a value has the bits block_sum gives it.
+template <int NV>
+__device__ __forceinline__ void block_sum_wide(double (&v)[NV], double* red)
+{
+	static_assert(NV <= 16, "block_sum_wide: at most 16 values");
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const int nw = (blockDim.x + 63) >> 6;  // <= 8: red holds 128 doubles
+#pragma unroll
+	for (int k = 0; k < NV; ++k)
+	{
+		v[k] = wave_sum(v[k]);
+	}
+	__syncthreads();  // red may still be read by a previous call
+	if (lane == kWaveResultLane)
+	{
+#pragma unroll
+		for (int k = 0; k < NV; ++k)
+		{
+			red[wave * 16 + k] = v[k];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < NV; ++k)
+	{
+		double s = red[k];
+		for (int w = 1; w < nw; ++w)
+		{
+			s += red[w * 16 + k];
+		}
+		v[k] = s;
+	}
+}
+
 // ---------------------------------------------------------------------------
 // Warp + 7x7 Gaussian splat of one unit's events into rows [r0, r0+rows) of its
 // 3W x 3H image (contrast_functor.h:38-88).  C = 1: value only (the T=double
