@@ -586,11 +586,16 @@ int ensure_device_modes(ebo_ctx* c, size_t nf)
 // the half's results come back, and `done` marks the end; nothing here waits.
 // The running windows of slots [s0, s1) as a kernel-argument list (LiveWindows), if the context is a grid of
 // windows, the caller vouches for one mode per window (windowSlots == P) and at most kLiveMax are running.
-bool live_windows_of(const ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, int windowSlots, LiveWindows& live)
+bool live_windows_of(const ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, int windowSlots, bool wantJac,
+					 LiveWindows& live)
 {
 	const bool noCompact = std::getenv("EBO_SOLVE_NO_COMPACT") != nullptr;  // (A/B and tests: read per round)
 	live.n = 0;
-	if (c->custom_n || c->P <= 0 || windowSlots != c->P || s0 % c->P != 0 || s1 % c->P != 0 || noCompact)
+	// A central-difference Jacobian round evaluates five flow sets and combines them (k_combine_variance /
+	// k_edge_central): those launches cover every unit and know neither the list nor the modes, so such a
+	// round takes the full path, which copies back only its own slots [s0, s1).
+	const bool central = wantJac && c->prm.grad == EBO_GRAD_CENTRAL;
+	if (c->custom_n || c->P <= 0 || windowSlots != c->P || s0 % c->P != 0 || s1 % c->P != 0 || noCompact || central)
 	{
 		return false;
 	}
@@ -624,7 +629,7 @@ int eval_begin(ebo_ctx* c, const double* flows, const unsigned char* modes, int 
 	// (Windows of a grid context: P flow slots and P + 1 units each, one mode per window.)
 	{
 		LiveWindows live;
-		if (live_windows_of(c, modes, s0, s1, windowSlots, live))
+		if (live_windows_of(c, modes, s0, s1, windowSlots, wantJac, live))
 		{
 			const size_t P = static_cast<size_t>(c->P);
 			for (int k = 0; k < live.n; ++k)
@@ -705,7 +710,7 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 	// a batch of windows of which some have finished: the running ones as a list in the kernel arguments, flows and
 	// results through the pinned buffers (as in eval_begin)
 	LiveWindows live;
-	if (modes && live_windows_of(c, modes, 0, nf, windowSlots, live))
+	if (modes && live_windows_of(c, modes, 0, nf, windowSlots, jac != nullptr, live))
 	{
 		const size_t P = static_cast<size_t>(c->P);
 		for (int k = 0; k < live.n; ++k)

@@ -90,8 +90,21 @@ struct Event
 	EventPolarity sign;
 };
 
+// CV_8U single-channel cv::Mat stand-in: what ImageSample carries to FeatureDetector::newImage
+// (data_types.h:39).  The event-warping path never reads pixels; the front-end hooks do.
+struct Image8
+{
+	int rows = 0;
+	int cols = 0;
+	std::vector<uint8_t> data;  // row-major
+	Image8() = default;
+	Image8(int r, int c) : rows(r), cols(c), data(static_cast<size_t>(r) * c, 0) {}
+};
+
 using EventSample = Sample<Event>;
+using ImageSample = Sample<Image8>;
 using EventSequence = std::deque<EventSample>;
+using ImageSequence = std::vector<ImageSample>;
 
 static_assert(sizeof(EventSample) == sizeof(ebo_event), "EventSample must match ebo_event");
 static_assert(offsetof(EventSample, timestamp) == offsetof(ebo_event, t_us), "timestamp offset");

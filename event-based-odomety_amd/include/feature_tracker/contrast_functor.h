@@ -26,7 +26,7 @@
 #include <string>
 #include <vector>
 
-#include "feature_detector.h"
+#include "types.h"
 
 #if defined(__has_include)
 #if __has_include(<ceres/ceres.h>)

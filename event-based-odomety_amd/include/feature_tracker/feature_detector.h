@@ -1,81 +1,63 @@
-// feature_tracker/feature_detector.h — tracker::FeatureDetector and
-// tracker::DetectorParams with the reference's names and call order
+// feature_tracker/feature_detector.h — tracker::FeatureDetector and tracker::DetectorParams: the
+// class the reference's unchanged front end holds
 // (implementation/feature_tracker/include/feature_tracker/feature_detector.h:10-120,
-// src/feature_detector.cpp:243-482,621-628), for the event-warping path only.  Every
-// method forwards to the C ABI (include/ebo.h); nothing is computed on the CPU here.
+// src/feature_detector.cpp).  Every member the front end calls is here under the reference's name:
 //
-// Drop-in use under the unchanged front end (tools/evaluator/src/evaluator.cpp:32-45):
-//     tracker_->addEvent(sample);
-//     if (window due) {
-//         tracker_->compensateEventsContrast(tracker_->getEvents());
-//         tracker_->integrateEvents(tracker_->getEvents());
-//         tracker_->clearEvents();
-//     }
-// Result images are CV_64F-like (tracker::Mat64, row-major doubles, rows x cols =
-// imageSize), valid until the next call — as the cv::Mat const& of the reference.
-// With OpenCV available, wrap without a copy:
-//     cv::Mat view(m.rows, m.cols, CV_64F, const_cast<double*>(m.ptr()));
+//   tools::Evaluator::eventCallback (tools/evaluator/src/evaluator.cpp:32-45)
+//       tracker_->addEvent(sample);
+//       tracker_->updatePatches(sample);
+//       if (window due) {
+//           tracker_->compensateEventsContrast(tracker_->getEvents());
+//           tracker_->integrateEvents(tracker_->getEvents());
+//           tracker_->clearEvents();
+//       }
+//   ~Evaluator (:15-21)    preExit, getArchivedPatches, getOptimizedFinalCosts
+//   getPatches (:23-30), reset (:101-118: DetectorParams::drawImages / imageSize), setTrackerParams (:120-123)
+//   visual_odometry::Keyframe(tracker_->getPatches(), ts) (visual_odometry/src/keyframe.cpp:5-14)
+//
+// Everything per-event / per-pixel forwards to the C ABI (include/ebo.h); the host side here is the
+// reference's bookkeeping (patch association, archive, optimizer user counts).  The three OpenCV-only
+// pieces of newImage — cv::goodFeaturesToTrack (:568-583), log image + cv::Sobel (:713-731) and
+// cv::calcOpticalFlowPyrLK (flow_estimator.cpp:86-108) — are outside the event-warping path: they are
+// taken as FrontEndHooks (three lambdas holding the reference's own OpenCV calls); without them
+// newImage / extractPatches / detectFeatures report EBO_ERR_UNSUPPORTED through the error policy.
+//
+// Result images are CV_64F-like (tracker::Mat64, row-major doubles, rows x cols = imageSize), valid
+// until the next call — as the cv::Mat const& of the reference.  With OpenCV available, wrap
+// without a copy:  cv::Mat view(m.rows, m.cols, CV_64F, const_cast<double*>(m.ptr()));
 #pragma once
 
+#include <cmath>
+#include <functional>
 #include <list>
+#include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../common/data_types.h"
+#include "optimizer.h"
+#include "patch.h"
+#include "tracked_patches.h"
+#include "types.h"
 
 namespace tracker
 {
-struct Size
-{
-	int width = 0;
-	int height = 0;
-	Size() = default;
-	Size(int w, int h) : width(w), height(h) {}
-};
-
-// cv::Rect2i stand-in; contains() is half-open like cv::Rect_::contains.
-struct Rect2i
-{
-	int x = 0, y = 0, width = 0, height = 0;
-	Rect2i() = default;
-	Rect2i(int x_, int y_, int w_, int h_) : x(x_), y(y_), width(w_), height(h_) {}
-	bool contains(const common::Point2i& p) const
-	{
-		return x <= p.x && p.x < x + width && y <= p.y && p.y < y + height;
-	}
-};
-
-// CV_64F single-channel image stand-in.
-class Mat64
-{
-   public:
-	int rows = 0;
-	int cols = 0;
-	Mat64() = default;
-	Mat64(int r, int c) : rows(r), cols(c), data_(static_cast<size_t>(r) * c, 0.0) {}
-	template <typename T = double>
-	T& at(int r, int c)
-	{
-		return data_[static_cast<size_t>(r) * cols + c];
-	}
-	template <typename T = double>
-	const T& at(int r, int c) const
-	{
-		return data_[static_cast<size_t>(r) * cols + c];
-	}
-	double* ptr() { return data_.data(); }
-	const double* ptr() const { return data_.data(); }
-
-   private:
-	std::vector<double> data_;
-};
-
-// The DetectorParams fields this path reads (feature_detector.h:17,21-30), same
-// names and defaults; the last block selects what the north star adds.
+// Every field of the reference's DetectorParams (feature_detector.h:10-31), same names, order and
+// defaults.  qualityLevel / minDistance / blockSize are read only by the detectFeatures hook's owner
+// (cv::goodFeaturesToTrack); the last block selects what the north star adds.
 struct DetectorParams
 {
+	double qualityLevel = 0.01;
+	double minDistance = 10;
+	double associationDistance = 5;
+	int32_t patchExtent = 12;
+	int32_t blockSize = 3;
 	Size imageSize = {240, 180};
+	bool drawImages = false;
+	OptimizerParams optimizerParams = {};
+	int initNumEvents = 75;
 	unsigned long maxNumEventsToStore = 15000;
 	bool useAverageFlow = true;
 	bool optimizeFlowTV = true;
@@ -85,6 +67,7 @@ struct DetectorParams
 	double compensateTVHuberLoss = 10;
 	double compensateScale = 1e-3;
 	unsigned int compensateMinNumEvents = 100;
+	size_t maxPatches = 100;
 
 	int device = 0;                 // HIP device ordinal
 	int loss = EBO_LOSS_EDGE;       // reference default; EBO_LOSS_VARIANCE = north-star objective
@@ -101,46 +84,32 @@ struct DetectorParams
 	int errorPolicy = ERRORS_THROW;
 };
 
+// The OpenCV-side pieces of FeatureDetector::newImage, which are not on the event-warping path.  With
+// OpenCV present an integrator fills them with the reference's own calls.
+struct FrontEndHooks
+{
+	// detectFeatures (:568-583): cv::goodFeaturesToTrack under mask_ (a border of patchExtent)
+	std::function<Corners(const common::Image8&)> detectFeatures;
+	// getLogImage + getGradients (:713-731): log(I/255 + 0.1), cv::Sobel(image / 8, CV_64F, dx, dy, 3)
+	std::function<void(const common::Image8&, Mat64& gradX, Mat64& gradY)> gradients;
+	// FlowEstimator::getFlow (flow_estimator.cpp:86-108): cv::calcOpticalFlowPyrLK from the previous image to
+	// this one for ONE point (cv::Point2f in and out); false = status 0.  Called from the second image on.
+	std::function<bool(float x, float y, float& nextX, float& nextY)> flow;
+	double patchTimeWithoutUpdateScale = 1e6;  // FlowEstimatorParams (flow_estimator.h:16)
+};
+
 class FeatureDetector
 {
    public:
 	explicit FeatureDetector(const DetectorParams& params) : params_(params)
 	{
-		ebo_params p;
-		ebo_default_params(&p);
-		p.device = params.device;
-		p.image_w = params.imageSize.width;
-		p.image_h = params.imageSize.height;
-		p.patch_w = params.patchCompensateSize.width;
-		p.patch_h = params.patchCompensateSize.height;
-		p.tv_weight = params.compensateTVweight;
-		p.tv_huber = params.compensateTVHuberLoss;
-		p.scale = params.compensateScale;
-		p.min_events = params.compensateMinNumEvents;
-		p.loss = params.loss;
-		p.grad = params.grad;
-		p.max_events = params.maxNumEventsToStore > 0 ? params.maxNumEventsToStore : 1;
-		p.max_windows = 1;
-		const int rc = ebo_create(&p, &ctx_);
-		if (rc != EBO_OK)
-		{
-			ctx_ = nullptr;
-			fail(rc, ebo_last_error(nullptr));
-			numPatchesX_ = p.patch_w > 0 ? p.image_w / p.patch_w : 0;
-			numPatchesY_ = p.patch_h > 0 ? p.image_h / p.patch_h : 0;
-		}
-		else
-		{
-			ebo_grid(ctx_, &numPatchesX_, &numPatchesY_);
-		}
-		compensatedEventImage_ = Mat64(p.image_h, p.image_w);
-		integratedEventImage_ = Mat64(p.image_h, p.image_w);
-		motionField_.assign(static_cast<size_t>(p.image_h) * p.image_w * 2, 0.0f);
-		patchFlows_.assign(static_cast<size_t>(numPatchesX_) * numPatchesY_ * 2, 0.0);
-		lastCompensation = common::timestamp_t(0);
+		createContext();
+		tracked_.reset(new TrackedPatches(ctx_, params_.imageSize, params_.initNumEvents));
+		reset();
 	}
 	~FeatureDetector()
 	{
+		tracked_.reset();
 		if (ctx_)
 		{
 			ebo_destroy(ctx_);
@@ -148,6 +117,189 @@ class FeatureDetector
 	}
 	FeatureDetector(const FeatureDetector&) = delete;
 	FeatureDetector& operator=(const FeatureDetector&) = delete;
+
+	// feature_detector.cpp:484-491
+	void preExit()
+	{
+		for (const Patch& patch : tracked_->getPatches())
+		{
+			archivedPatches_.push_back(patch);
+		}
+	}
+
+	void setFrontEndHooks(const FrontEndHooks& hooks) { hooks_ = hooks; }
+
+	// feature_detector.cpp:493-541.  Needs the detectFeatures and gradients hooks (EBO_ERR_UNSUPPORTED
+	// without them); without the flow hook new patches stay un-initialised, as before the reference's
+	// second image (flow_estimator.cpp:29-32).
+	void newImage(const common::ImageSample& image)
+	{
+		if (!hooks_.detectFeatures || !hooks_.gradients)
+		{
+			fail(EBO_ERR_UNSUPPORTED,
+				 "newImage needs the OpenCV front end (goodFeaturesToTrack, Sobel, calcOpticalFlowPyrLK): "
+				 "install FrontEndHooks");
+			return;
+		}
+		guarded([&] {
+			extractPatchesImpl(image);
+			// flowEstimator_->addImage / getFlowPatches (flow_estimator.cpp:16-85)
+			if (imageCounter_ < 2)
+			{
+				imageCounter_++;
+			}
+			if (imageCounter_ == 2 && hooks_.flow)
+			{
+				flowPatches();
+			}
+			std::vector<Patch*> all;
+			for (Patch& patch : tracked_->getPatches())
+			{
+				all.push_back(&patch);
+			}
+			tracked_->updateNumOfEvents(all);
+			if (params_.drawImages)
+			{
+				warpByFrame(all);
+			}
+			auto& optimizers = tracked_->optimizers();
+			Patches& patches = tracked_->getPatches();
+			for (auto patchIt = patches.begin(); patchIt != patches.end();)
+			{
+				if (patchIt->isLost())
+				{
+					archivedPatches_.push_back(*patchIt);
+					auto opt = optimizers.find(patchIt->getInitTime().count());
+					if (opt != optimizers.end() && opt->second)
+					{
+						opt->second->deleteUser();
+					}
+					patchIt = patches.erase(patchIt);
+					continue;
+				}
+				++patchIt;
+			}
+			for (auto optIt = optimizers.begin(); optIt != optimizers.end();)
+			{
+				if (!optIt->second || !optIt->second->isUsed())
+				{
+					optIt = optimizers.erase(optIt);
+				}
+				else
+				{
+					++optIt;
+				}
+			}
+		});
+	}
+
+	// feature_detector.cpp:543-566
+	void extractPatches(const common::ImageSample& image)
+	{
+		if (!hooks_.detectFeatures || !hooks_.gradients)
+		{
+			fail(EBO_ERR_UNSUPPORTED, "extractPatches needs the detectFeatures and gradients hooks");
+			return;
+		}
+		guarded([&] { extractPatchesImpl(image); });
+	}
+
+	// feature_detector.cpp:568-583
+	Corners detectFeatures(const common::Image8& image)
+	{
+		if (!hooks_.detectFeatures)
+		{
+			fail(EBO_ERR_UNSUPPORTED, "detectFeatures is cv::goodFeaturesToTrack: install FrontEndHooks::detectFeatures");
+			return Corners();
+		}
+		status_ = EBO_OK;
+		return hooks_.detectFeatures(image);
+	}
+
+	// feature_detector.cpp:585-619: the reference's per-event call
+	void updatePatches(const common::EventSample& event)
+	{
+		guarded([&] { tracked_->updatePatches(event); });
+	}
+	// the same for a chunk of the stream: all patches advance in lock-step rounds, one launch per stage
+	// (tracked_patches.h); per patch the sequence of addEvent / optimize calls is the per-event one
+	void updatePatches(const std::vector<common::EventSample>& chunk)
+	{
+		guarded([&] { tracked_->updatePatches(chunk); });
+	}
+
+	// feature_detector.cpp:630-664.  The reference dereferences optimizers_[timestamp] (created by
+	// extractPatches); called without one (its own associatedPatchesTest does) the user count is skipped.
+	void associatePatches(Patches& newPatches, const common::timestamp_t& timestamp)
+	{
+		Patches& patches = tracked_->getPatches();
+		for (auto& patch : patches)
+		{
+			const auto corner = patch.toCorner();
+			for (auto& newPatch : newPatches)
+			{
+				const auto newCorner = newPatch.toCorner();
+				const double dx = corner.x - newCorner.x, dy = corner.y - newCorner.y;
+				if (newPatch.getTrackId() == -1 && std::sqrt(dx * dx + dy * dy) < params_.associationDistance)
+				{
+					newPatch.setTrackId(patch.getTrackId());
+					break;
+				}
+			}
+			patch.setTs(timestamp);
+			patch.addTrajectoryPosition();
+		}
+		auto& optimizers = tracked_->optimizers();
+		for (auto& newPatch : newPatches)
+		{
+			if (newPatch.getTrackId() == -1 && patches.size() < params_.maxPatches)
+			{
+				newPatch.setTrackId(static_cast<TrackId>(nextTrackId_));
+				patches.push_back(newPatch);  // newPatch.setGrad(gradX_, gradY_): the frame's Optimizer holds them
+				auto opt = optimizers.find(timestamp.count());
+				if (opt != optimizers.end() && opt->second)
+				{
+					opt->second->addUser();
+				}
+				nextTrackId_++;
+			}
+		}
+	}
+
+	// feature_detector.cpp:666-711 (the estimate on the device against the latest frame's gradients)
+	void updateNumOfEvents(Patch& patch)
+	{
+		guarded([&] { tracked_->updateNumOfEvents(patch); });
+	}
+
+	void setPatches(const Patches& patches) { tracked_->setPatches(patches); }  // feature_detector.h:67
+	void setTrackId(TrackId trackId) { nextTrackId_ = static_cast<size_t>(trackId); }
+	Patches const& getPatches() const { return tracked_->getPatches(); }
+	Patches& getPatches() { return tracked_->getPatches(); }
+	Corners const& getFeatures() const { return corners_; }
+	Patches const& getArchivedPatches() const { return archivedPatches_; }
+	// feature_detector.h:80-83: optimizers_.begin()->second->getFinalCosts() (undefined there when no
+	// optimizer exists; empty here).  optimizers_ is ordered by frame time here: begin() = oldest frame in use.
+	std::vector<tracker::OptimizerFinalLoss> getOptimizedFinalCosts() const
+	{
+		const auto& optimizers = tracked_->optimizers();
+		if (optimizers.empty() || !optimizers.begin()->second)
+		{
+			return {};
+		}
+		return optimizers.begin()->second->getFinalCosts();
+	}
+	// optimizers_[image.timestamp.count()] for callers that bring patches in through setPatches
+	void setOptimizer(const common::timestamp_t& initTime, std::shared_ptr<Optimizer> optimizer)
+	{
+		tracked_->setOptimizer(initTime, std::move(optimizer));
+	}
+	// gradX_ / gradY_ (:554-555) for callers that do not go through newImage
+	void setGradients(const Mat64& gradX, const Mat64& gradY)
+	{
+		guarded([&] { tracked_->setGradients(gradX, gradY); });
+	}
+	TrackedPatches& tracked() { return *tracked_; }
 
 	// feature_detector.cpp:621-628
 	void addEvent(const common::EventSample& event)
@@ -306,7 +458,41 @@ class FeatureDetector
 	const ebo_summary& getLastSummary() const { return lastSummary_; }
 	int numPatchesX() const { return numPatchesX_; }
 	int numPatchesY() const { return numPatchesY_; }
-	void setParams(const DetectorParams& params) { params_.maxNumEventsToStore = params.maxNumEventsToStore; }
+	// feature_detector.cpp:733-741: params_ = params; every optimizer takes optimizerParams; reset().
+	// The device context is re-created when a field it was built from changed.
+	void setParams(const tracker::DetectorParams& params)
+	{
+		const bool rebuild = params.imageSize.width != params_.imageSize.width ||
+							 params.imageSize.height != params_.imageSize.height ||
+							 params.patchCompensateSize.width != params_.patchCompensateSize.width ||
+							 params.patchCompensateSize.height != params_.patchCompensateSize.height ||
+							 params.compensateTVweight != params_.compensateTVweight ||
+							 params.compensateTVHuberLoss != params_.compensateTVHuberLoss ||
+							 params.compensateScale != params_.compensateScale ||
+							 params.compensateMinNumEvents != params_.compensateMinNumEvents ||
+							 params.maxNumEventsToStore != params_.maxNumEventsToStore || params.loss != params_.loss ||
+							 params.grad != params_.grad || params.device != params_.device;
+		params_ = params;
+		for (const auto& opt : tracked_->optimizers())
+		{
+			if (opt.second)
+			{
+				opt.second->setParams(params_.optimizerParams);
+			}
+		}
+		tracked_->setInitNumEvents(params_.initNumEvents);
+		if (rebuild || ctx_ == nullptr)
+		{
+			if (ctx_)
+			{
+				ebo_destroy(ctx_);
+				ctx_ = nullptr;
+			}
+			createContext();
+			tracked_->rebind(ctx_, params_.imageSize);
+		}
+		reset();
+	}
 	ebo_ctx* handle() { return ctx_; }
 
 	// DetectorParams::ERRORS_STATUS: the EBO_* code and message of the LAST call (EBO_OK / "" after
@@ -316,6 +502,143 @@ class FeatureDetector
 	const std::string& lastError() const { return lastError_; }
 
    private:
+	void createContext()
+	{
+		ebo_params p;
+		ebo_default_params(&p);
+		p.device = params_.device;
+		p.image_w = params_.imageSize.width;
+		p.image_h = params_.imageSize.height;
+		p.patch_w = params_.patchCompensateSize.width;
+		p.patch_h = params_.patchCompensateSize.height;
+		p.tv_weight = params_.compensateTVweight;
+		p.tv_huber = params_.compensateTVHuberLoss;
+		p.scale = params_.compensateScale;
+		p.min_events = params_.compensateMinNumEvents;
+		p.loss = params_.loss;
+		p.grad = params_.grad;
+		p.max_events = params_.maxNumEventsToStore > 0 ? params_.maxNumEventsToStore : 1;
+		p.max_windows = 1;
+		const int rc = ebo_create(&p, &ctx_);
+		if (rc != EBO_OK)
+		{
+			ctx_ = nullptr;
+			numPatchesX_ = p.patch_w > 0 ? p.image_w / p.patch_w : 0;
+			numPatchesY_ = p.patch_h > 0 ? p.image_h / p.patch_h : 0;
+			fail(rc, ebo_last_error(nullptr));
+		}
+		else
+		{
+			ebo_grid(ctx_, &numPatchesX_, &numPatchesY_);
+		}
+		patchFlows_.assign(static_cast<size_t>(numPatchesX_) * numPatchesY_ * 2, 0.0);
+	}
+
+	// feature_detector.cpp:32-51 (mask_ belongs to the detectFeatures hook's owner)
+	void reset()
+	{
+		motionField_.assign(static_cast<size_t>(params_.imageSize.height) * params_.imageSize.width * 2, 0.0f);
+		compensatedEventImage_ = Mat64(params_.imageSize.height, params_.imageSize.width);
+		integratedEventImage_ = Mat64(params_.imageSize.height, params_.imageSize.width);
+		lastCompensation = common::timestamp_t(0);
+		lastEvents_.clear();
+	}
+
+	// feature_detector.cpp:543-566
+	void extractPatchesImpl(const common::ImageSample& image)
+	{
+		corners_ = hooks_.detectFeatures(image.value);
+		Patches newPatches;
+		for (const auto& corner : corners_)
+		{
+			newPatches.emplace_back(Patch(corner, params_.patchExtent, image.timestamp));
+		}
+		Mat64 gradX, gradY;
+		hooks_.gradients(image.value, gradX, gradY);
+		auto optimizer = std::make_shared<Optimizer>(params_.optimizerParams, params_.imageSize);
+		optimizer->setGrad(gradX, gradY);
+		tracked_->setOptimizer(image.timestamp, optimizer);
+		tracked_->setGradients(gradX, gradY);  // gradX_ / gradY_: what updateNumOfEvents warps
+		associatePatches(newPatches, image.timestamp);
+	}
+
+	// FlowEstimator::getFlowPatches (flow_estimator.cpp:27-85), the point flow through the hook
+	void flowPatches()
+	{
+		for (Patch& patch : tracked_->getPatches())
+		{
+			if (patch.isInit())
+			{
+				continue;
+			}
+			const Corner corner = patch.toCorner();
+			float nx = 0.f, ny = 0.f;
+			if (!hooks_.flow(static_cast<float>(corner.x), static_cast<float>(corner.y), nx, ny))
+			{
+				patch.setLost();
+				continue;
+			}
+			const double dirX = nx - corner.x;
+			const double dirY = ny - corner.y;
+			const double flowDir = std::atan2(dirY, dirX);
+			common::Pose2d warp;
+			warp.data()[2] = -dirX;
+			warp.data()[3] = -dirY;
+			patch.setWarp(warp);
+			patch.setFlowDir(flowDir);
+			patch.setTimeWithoutUpdate(common::timestamp_t(static_cast<int64_t>(
+				hooks_.patchTimeWithoutUpdateScale / std::fmax(1e-1, std::sqrt(dirX * dirX + dirY * dirY)))));
+			const Corner newCorner = patch.toCorner();
+			if (newCorner.x <= 5 || newCorner.y <= 5 || newCorner.x >= params_.imageSize.width - 5 ||
+				newCorner.y >= params_.imageSize.height - 5)
+			{
+				patch.setLost();
+			}
+		}
+	}
+
+	// patch.warpImage() for every patch (:505-511), one launch per frame the patches came from
+	void warpByFrame(const std::vector<Patch*>& all)
+	{
+		std::map<int64_t, std::vector<Patch*>> byFrame;
+		for (Patch* p : all)
+		{
+			byFrame[p->getInitTime().count()].push_back(p);
+		}
+		for (auto& group : byFrame)
+		{
+			auto opt = tracked_->optimizers().find(group.first);
+			if (opt != tracked_->optimizers().end() && opt->second)
+			{
+				tracked_->warpImages(group.second, opt->second->handle());
+			}
+		}
+	}
+
+	// runs the tracked-patch calls (which throw) under the detector's error policy
+	template <class F>
+	void guarded(F&& f)
+	{
+		if (params_.errorPolicy == DetectorParams::ERRORS_THROW)
+		{
+			f();
+			status_ = EBO_OK;
+			lastError_.clear();
+			return;
+		}
+		try
+		{
+			f();
+			status_ = EBO_OK;
+			lastError_.clear();
+		}
+		catch (const std::exception& e)
+		{
+			status_ = ctx_ ? EBO_ERR_HIP : EBO_ERR_NO_DEVICE;
+			lastError_ = e.what();
+		}
+	}
+
 	bool check(int rc)
 	{
 		if (ctx_ == nullptr)
@@ -345,6 +668,12 @@ class FeatureDetector
 	std::string lastError_;
 
 	DetectorParams params_;
+	FrontEndHooks hooks_;
+	std::unique_ptr<TrackedPatches> tracked_;
+	Corners corners_;
+	size_t nextTrackId_ = 0;
+	Patches archivedPatches_;
+	size_t imageCounter_ = 0;
 	ebo_summary lastFieldSummary_{};
 	ebo_ctx* ctx_ = nullptr;
 	int numPatchesX_ = 0, numPatchesY_ = 0;

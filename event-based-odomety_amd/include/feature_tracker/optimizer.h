@@ -23,8 +23,8 @@
 #include <vector>
 
 #include "../common/data_types.h"
-#include "feature_detector.h"
 #include "patch.h"
+#include "types.h"
 
 namespace tracker
 {

@@ -11,28 +11,14 @@
 #include <cmath>
 #include <cstdint>
 #include <deque>
+#include <list>
 #include <vector>
 
 #include "../common/data_types.h"
-#include "feature_detector.h"
+#include "types.h"
 
 namespace tracker
 {
-using Corner = common::Point2d;
-using TrackId = int32_t;
-
-// cv::Rect2d stand-in; contains() is half-open on the integer point, as cv::Rect_::contains.
-struct Rect2d
-{
-	double x = 0, y = 0, width = 0, height = 0;
-	Rect2d() = default;
-	Rect2d(double x_, double y_, double w_, double h_) : x(x_), y(y_), width(w_), height(h_) {}
-	bool contains(const common::Point2i& p) const
-	{
-		return x <= p.x && p.x < x + width && y <= p.y && p.y < y + height;
-	}
-};
-
 class Patch
 {
    public:
@@ -204,5 +190,7 @@ class Patch
 	std::vector<common::Sample<common::Point2d>> trajectory_;
 	std::vector<double> finalCosts_;
 };
+
+using Patches = std::list<Patch>;  // patch.h:132 (a list: element addresses stay valid while patches are erased)
 
 }  // namespace tracker

@@ -1,8 +1,9 @@
 // feature_tracker/tracked_patches.h — the tracked-patch half of tracker::FeatureDetector with
 // the reference's names: `patches_`, `optimizers_`, `updatePatches`, `updateNumOfEvents`
 // (implementation/feature_tracker/src/feature_detector.cpp:585-619,666-711; members
-// feature_detector.h:100-118).  A class of its own here only because of header layering
-// (tracker::Patch needs Mat64 from feature_detector.h); a FeatureDetector owns one.
+// feature_detector.h:100-118).  tracker::FeatureDetector owns one (sharing its device context) and
+// forwards updatePatches / getPatches / setPatches / updateNumOfEvents to it; the class is usable
+// on its own too (it then owns a context).
 //
 //   updatePatches(const common::EventSample&)        the reference's per-event call, verbatim order:
 //        for every patch that is not lost: addEvent if the event is inside its rect; then, if the
@@ -44,8 +45,6 @@
 
 namespace tracker
 {
-using Patches = std::vector<Patch>;
-
 class TrackedPatches
 {
    public:
@@ -66,7 +65,19 @@ class TrackedPatches
 			throw std::runtime_error(std::string("tracker::TrackedPatches: ") + ebo_last_error(nullptr));
 		}
 	}
-	~TrackedPatches() { ebo_destroy(ctx_); }
+	// the same on a context somebody else owns (tracker::FeatureDetector's): routing and the event-count
+	// estimate keep their state apart from the compensation window, so one context serves both
+	TrackedPatches(ebo_ctx* shared, const Size& imageSize, int initNumEvents)
+		: imageSize_(imageSize), initNumEvents_(initNumEvents), ctx_(shared), ownsCtx_(false)
+	{
+	}
+	~TrackedPatches()
+	{
+		if (ownsCtx_ && ctx_)
+		{
+			ebo_destroy(ctx_);
+		}
+	}
 	TrackedPatches(const TrackedPatches&) = delete;
 	TrackedPatches& operator=(const TrackedPatches&) = delete;
 
@@ -74,6 +85,19 @@ class TrackedPatches
 	Patches const& getPatches() const { return patches_; }
 	void setPatches(const Patches& patches) { patches_ = patches; }  // feature_detector.h:72
 	void addPatch(const Patch& patch) { patches_.push_back(patch); }
+	void setInitNumEvents(int initNumEvents) { initNumEvents_ = initNumEvents; }
+	// a FeatureDetector that re-creates its context (setParams with another image size) hands the new one over
+	void rebind(ebo_ctx* shared, const Size& imageSize)
+	{
+		if (!ownsCtx_)
+		{
+			ctx_ = shared;
+			imageSize_ = imageSize;
+			haveGradients_ = false;
+		}
+	}
+	std::map<int64_t, std::shared_ptr<Optimizer>>& optimizers() { return optimizers_; }
+	const std::map<int64_t, std::shared_ptr<Optimizer>>& optimizers() const { return optimizers_; }
 
 	// optimizers_[image.timestamp.count()] of the reference (:560-563): the optimizer holding the
 	// gradient grid of the image a patch was extracted from, keyed by the patch's init time
@@ -232,11 +256,17 @@ class TrackedPatches
 		const std::vector<ebo_event> ev = common::toEboEvents(chunk);
 		check(ebo_route_set_events(ctx_, ev.data(), n));
 		const size_t np = patches_.size();
+		std::vector<Patch*> at;  // patches_ is a list (the reference's type): index it once
+		at.reserve(np);
+		for (Patch& p : patches_)
+		{
+			at.push_back(&p);
+		}
 		std::vector<uint32_t> cursor(np, 0);
 		std::vector<int> live;  // patches still consuming the chunk
 		for (size_t i = 0; i < np; ++i)
 		{
-			Patch& p = patches_[i];
+			Patch& p = *at[i];
 			if (p.isLost())
 			{
 				continue;
@@ -270,7 +300,7 @@ class TrackedPatches
 			uint32_t cap = 1;
 			for (int j = 0; j < k; ++j)
 			{
-				const Patch& p = patches_[live[j]];
+				const Patch& p = *at[live[j]];
 				const Rect2d& r = p.getPatch();
 				rects[4 * j + 0] = r.x;
 				rects[4 * j + 1] = r.y;
@@ -291,7 +321,7 @@ class TrackedPatches
 			for (int j = 0; j < k; ++j)
 			{
 				const int i = live[j];
-				Patch& p = patches_[i];
+				Patch& p = *at[i];
 				if (take[j] == 0)
 				{
 					const common::EventSample& e = chunk[cursor[i]];
@@ -330,7 +360,7 @@ class TrackedPatches
 			live.clear();
 			for (int i : still)
 			{
-				if (!patches_[i].isLost() && cursor[i] < n)
+				if (!at[i]->isLost() && cursor[i] < n)
 				{
 					live.push_back(i);
 				}
@@ -362,6 +392,7 @@ class TrackedPatches
 	Size imageSize_;
 	int initNumEvents_;
 	ebo_ctx* ctx_ = nullptr;
+	bool ownsCtx_ = true;
 	Patches patches_;
 	std::map<int64_t, std::shared_ptr<Optimizer>> optimizers_;
 	std::function<size_t(const Patch&)> estimator_;

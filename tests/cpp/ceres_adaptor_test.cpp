@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../event-based-odomety_amd/include/feature_tracker/contrast_functor.h"
+#include "../../event-based-odomety_amd/include/feature_tracker/feature_detector.h"
 #include "../../event-based-odomety_amd/csrc/host_lm.h"
 
 #ifndef EBO_HAVE_CERES

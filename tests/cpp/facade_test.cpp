@@ -81,6 +81,13 @@ static std::vector<orc_event> toOracle(const std::list<common::EventSample>& l)
 	return out;
 }
 
+// tracker::Patches is a std::list (the reference's type)
+template <class L>
+static auto nth(L& l, size_t i) -> decltype(*l.begin())
+{
+	return *std::next(l.begin(), static_cast<std::ptrdiff_t>(i));
+}
+
 int main()
 {
 	const auto samples = makeEvents(20000);
@@ -499,8 +506,8 @@ int main()
 		const common::timestamp_t timestamp(0);
 		tracker::Patches patches = {tracker::Patch({0, 0}, 11, timestamp), tracker::Patch({5, 5}, 11, timestamp),
 									tracker::Patch({20, 20}, 11, timestamp)};
-		tracker::TrackedPatches detector(tracker::Size(240, 180)), chunked(tracker::Size(240, 180));
-		detector.setPatches(patches);
+		tracker::TrackedPatches perEvent(tracker::Size(240, 180)), chunked(tracker::Size(240, 180));
+		perEvent.setPatches(patches);
 		chunked.setPatches(patches);
 		std::vector<common::EventSample> all;
 		std::srand(7);
@@ -510,7 +517,7 @@ int main()
 			event.timestamp = common::timestamp_t(i);
 			event.value.point = {std::rand() % 30, std::rand() % 30};
 			event.value.sign = std::rand() % 2 == 1 ? common::POSITIVE : common::NEGATIVE;
-			detector.updatePatches(event);
+			perEvent.updatePatches(event);
 			all.push_back(event);
 			for (auto& patch : patches)
 			{
@@ -521,13 +528,13 @@ int main()
 			}
 		}
 		chunked.updatePatches(all);
-		for (const tracker::TrackedPatches* d : {&detector, &chunked})
+		for (const tracker::TrackedPatches* d : {&perEvent, &chunked})
 		{
 			EXPECT_TRUE(d->getPatches().size() == patches.size());
 			for (size_t i = 0; i < patches.size(); ++i)
 			{
-				const auto& got = d->getPatches()[i].getEvents();
-				const auto& want = patches[i].getEvents();
+				const auto& got = nth(d->getPatches(), i).getEvents();
+				const auto& want = nth(patches, i).getEvents();
 				EXPECT_TRUE(got.size() == want.size() && !want.empty());
 				for (size_t k = 0; k < got.size() && k < want.size(); ++k)
 				{
@@ -643,8 +650,8 @@ int main()
 		int adapted = 0;
 		for (size_t i = 0; i < seq.getPatches().size(); ++i)
 		{
-			const tracker::Patch& p = seq.getPatches()[i];
-			const tracker::Patch& q = bat.getPatches()[i];
+			const tracker::Patch& p = nth(seq.getPatches(), i);
+			const tracker::Patch& q = nth(bat.getPatches(), i);
 			EXPECT_TRUE(p.isLost() == q.isLost() && p.isInit() == q.isInit());
 			EXPECT_TRUE(p.getFinalCosts().size() == q.getFinalCosts().size());
 			EXPECT_TRUE(p.getTrajectory().size() == q.getTrajectory().size());
@@ -729,10 +736,10 @@ int main()
 						std::chrono::duration<double, std::milli>(t2 - t1).count(), o2->getFinalCosts().size(),
 						b100.lastRounds());
 			EXPECT_TRUE(o1->getFinalCosts().size() == o2->getFinalCosts().size());
-			EXPECT_TRUE(s100.getPatches()[57].getPatch().x == b100.getPatches()[57].getPatch().x);
+			EXPECT_TRUE(nth(s100.getPatches(), 57).getPatch().x == nth(b100.getPatches(), 57).getPatch().x);
 		}
-		EXPECT_TRUE(seq.getPatches()[4].getFinalCosts().empty());   // never initialised
-		EXPECT_TRUE(seq.getPatches()[5].isLost() && seq.getPatches()[5].getFinalCosts().size() == 1);  // centre within 5 px of the border
+		EXPECT_TRUE(nth(seq.getPatches(), 4).getFinalCosts().empty());   // never initialised
+		EXPECT_TRUE(nth(seq.getPatches(), 5).isLost() && nth(seq.getPatches(), 5).getFinalCosts().size() == 1);  // centre within 5 px of the border
 	}
 
 	// ---- Patch::warpImage: the reference's warpImageTest (patch_test.cpp:62-108) through the facade ----

@@ -85,3 +85,29 @@ def test_reference_replayer_and_trajectory_scenarios(ebo):
     out = subprocess.run([os.path.join(CPP, "tools_test"), os.path.join(HERE, "golden", "replayer")],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "all passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_front_end_lines_compile_and_host_subset(ebo):
+    """CPU: the front end's own statements (evaluator.cpp:15-45,106-109,120-123; keyframe.cpp:5-14) and the
+    reference's updatePatchTest / associatedPatchesTest compile verbatim under -Wall -Wextra against the
+    facade's ONE tracker::FeatureDetector; the host-only subset (patch bookkeeping, every DetectorParams
+    field with the reference's default, EBO_ERR_UNSUPPORTED for newImage without hooks) runs without a device."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "front_end_lines_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+    run = subprocess.run([os.path.join(CPP, "front_end_lines_test"), "--cpu"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "all passed" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_front_end_lines_run_like_the_pair(ebo):
+    """The evaluator's event loop through the one FeatureDetector (tracker + compensation on one device
+    context): patches, flows and both images bit-equal to the stand-alone TrackedPatches + FeatureDetector
+    pair; the newImage life cycle through FrontEndHooks; Keyframe over getPatches()."""
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "front_end_lines_test"])
+    out = subprocess.run([os.path.join(CPP, "front_end_lines_test")], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-4000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-4000:]
+    assert "all passed" in out.stdout

@@ -528,6 +528,35 @@ def test_thinned_out_rounds_as_window_lists_keep_the_bits(ebo, synth, monkeypatc
     assert len({s[0] for s in out[0][1]}) > 1  # the windows do not all stop together: some rounds were thinned out
 
 
+@pytest.mark.parametrize("loss", ["variance", "edge"])
+def test_central_difference_rounds_never_take_the_window_list(ebo, synth, monkeypatch, loss):
+    """A central-difference Jacobian round launches five flow sets and a combine kernel over EVERY unit; those
+    launches know no window list.  Such rounds must take the full path (which copies back only the half's own
+    slots): in the pipelined driver (41 windows, two halves in flight) the solve equals, bit for bit, the
+    list-free and the unpipelined one."""
+    n = 41
+    ev, offsets, _ = synth.make_stream(0, n, n_events=4000)
+    kw = dict(image_w=240, image_h=180, patch_w=20, patch_h=20, grad=ebo.GRAD_CENTRAL,
+              loss=ebo.LOSS_VARIANCE if loss == "variance" else ebo.LOSS_EDGE, max_events=len(ev), max_windows=n)
+    out = []
+    for env in (None, "EBO_SOLVE_NO_COMPACT", "EBO_SOLVE_NO_PIPELINE"):
+        for k in ("EBO_SOLVE_NO_COMPACT", "EBO_SOLVE_NO_PIPELINE"):
+            monkeypatch.delenv(k, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        with ebo.Context(**kw) as c:
+            c.set_windows(ev, offsets)
+            opts = ebo.default_solver()
+            opts.max_num_iterations = 10
+            flows, summ = c.solve(opts)
+            out.append((flows.copy(), [(s.iterations, s.final_cost, s.termination, s.num_evals_cost, s.num_evals_jac) for s in summ]))
+    for k in ("EBO_SOLVE_NO_COMPACT", "EBO_SOLVE_NO_PIPELINE"):
+        monkeypatch.delenv(k, raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[2][0]) and out[0][1] == out[2][1]
+    assert len({s[0] for s in out[0][1]}) > 1  # windows stop at different rounds: thinned-out rounds happened
+
+
 def test_pipelined_lock_step_solve_equals_the_plain_one(ebo, synth, monkeypatch):
     """With four or more windows the TV-coupled host LM runs two halves in flight (one half's LM steps
     on the host while the device evaluates the other): per window the same requests in the same
