@@ -320,6 +320,10 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--preheat", type=int, default=None,
+                    help="untimed steps BEFORE the W warm-up steps that bring the GPU's clocks up (the same count on every "
+                         "rank: steps may hold collectives).  profiles/r04_step_loop.txt: the first ~10 ms of kernels after the "
+                         "idle set-up phase run ~6 %% slower, whatever launches them")
     args = ap.parse_args()
     if args.replicas:
         args.workload = "replicas"
@@ -576,6 +580,13 @@ def main():
                                     "" if args.no_c4_image else " and reduce of the %d x %d count images (moved as int32: exact, half the bytes of f64)" % (cfg["image"][0], cfg["image"][1]))}
 
     # ---- the timed region: W warm-up steps, barrier, EXACTLY K steps, barrier -----------------
+    # Before it, untimed: the GPU idled through the set-up (event generation, uploads) and its first ~10 ms of
+    # kernels run at lower clocks.  With the driver's `--steps 20 --warmup 5` that ramp was 6 % of round 3's
+    # headline (ms_per_step 0.568 against a kernel of 0.533 ms by HIP events in the same run).
+    if args.preheat is None:
+        args.preheat = {"eval": 200, "c4": 6, "replicas": 20}[workload]
+    for _ in range(args.preheat):
+        step()
     for _ in range(args.warmup):
         step()
     comm.barrier()
@@ -889,7 +900,7 @@ def main():
             "metric": "Mevents/s warped+scored (value+Jacobian of the variance-contrast objective)"
                       if workload != "c4" else "Mevents/s warped+scored (event-evaluations of the per-patch solves)",
             "value": value, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "preheat_steps_untimed": args.preheat, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (workload == "c4" and args.strong) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": config,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -137,6 +137,11 @@ def lib():
         _lib.ebo_last_error.argtypes = [C.c_void_p]
         _lib.ebo_destroy.restype = None
         _lib.ebo_destroy.argtypes = [C.c_void_p]
+        _lib.ebo_graph_destroy.restype = None
+        _lib.ebo_graph_destroy.argtypes = [C.c_void_p]
+        _lib.ebo_graph_begin.argtypes = [C.c_void_p]
+        _lib.ebo_graph_end.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.ebo_graph_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.ebo_lm_destroy.restype = None
         _lib.ebo_lm_destroy.argtypes = [C.c_void_p]
         _lib.ebo_lm_request.argtypes = [C.c_void_p, C.c_void_p]
@@ -339,6 +344,27 @@ def make_events(x, y, t_us, sign=None):
     return ev
 
 
+class Graph:
+    """A recorded step (ebo_graph): launch(times) replays it back to back on the context's stream."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._g = ctx, handle
+
+    def launch(self, times=1):
+        self._ctx._check(lib().ebo_graph_launch(self._ctx._h, self._g, int(times)))
+
+    def close(self):
+        if self._g:
+            lib().ebo_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """Owns one ebo_ctx (one device, one stream).  Mirrors include/ebo.h 1:1."""
 
@@ -381,6 +407,18 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ebo_synchronize(self._h))
+
+    def record(self, fn):
+        """Record the asynchronous *_device calls fn() makes into a HIP graph (ebo_graph_begin / _end).
+        Run fn() once before (work tables are allocated on first use).  -> Graph"""
+        self._check(lib().ebo_graph_begin(self._h))
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = lib().ebo_graph_end(self._h, C.byref(g))
+        self._check(rc)
+        return Graph(self, g)
 
     def patch_rect(self, px, py):
         v = [C.c_int() for _ in range(4)]

@@ -1530,6 +1530,10 @@ int ebo_set_stream(ebo_ctx* c, void* hip_stream)
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (c->own_stream && c->stream)
 	{
 		(void)hipStreamSynchronize(c->stream);
@@ -1545,6 +1549,10 @@ int ebo_synchronize(ebo_ctx* c)
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	return c->hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
 }
@@ -1575,6 +1583,10 @@ int ebo_eval(ebo_ctx* c, const double* flows, double* r, double* jac)
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!flows || !r)
 	{
@@ -1607,6 +1619,10 @@ int ebo_contrast_image(ebo_ctx* c, int window, int patch, const double* flow, in
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!flow || !image || (channels != 1 && channels != 3) || window < 0 ||
 		window >= c->n_windows || patch < 0 || patch >= c->cur_patches())
@@ -1661,6 +1677,10 @@ int ebo_solve(ebo_ctx* c, const ebo_solver_opts* o, double* flows_out, ebo_summa
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!flows_out)
 	{
 		return c->fail(EBO_ERR_ARG, "null flows_out");
@@ -1713,6 +1733,10 @@ int ebo_count_image(ebo_ctx* c, int mode, const void* aux, double* image)
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	// EBO_COUNT_FIELD with aux == NULL: the field left on the device by
 	// ebo_init_motion_field (one window only: the field belongs to the context)
@@ -1789,6 +1813,10 @@ int ebo_edge_work_stats(ebo_ctx* c, const double* d_flows, int want_jac, uint64_
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!d_flows || !out)
 	{
 		return c->fail(EBO_ERR_ARG, "null pointer");
@@ -1833,6 +1861,10 @@ int ebo_lds_rates(ebo_ctx* c, double* gops)
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!gops)
 	{
@@ -1885,6 +1917,10 @@ int ebo_stream_yardstick_device(ebo_ctx* c, double* d_image, uint64_t* bytes)
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!d_image)
 	{
 		return c->fail(EBO_ERR_ARG, "null image");
@@ -1929,6 +1965,10 @@ int ebo_count_image_shard_device(ebo_ctx* c, int n_windows, const int64_t* windo
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (n_windows <= 0 || !window_t_ref_us || !d_flows_grid || !d_image)
 	{
@@ -1996,6 +2036,10 @@ int ebo_count_image_shard(ebo_ctx* c, int n_windows, const int64_t* window_t_ref
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (n_windows <= 0 || !window_t_ref_us || !flows_grid || !image)
 	{
 		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image_shard");
@@ -2031,6 +2075,10 @@ int ebo_compensate_events_contrast(ebo_ctx* c, const ebo_event* ev, size_t n,
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!ev || n == 0 || !flows_out)
 	{
 		return c->fail(EBO_ERR_ARG, "empty window or null output");
@@ -2058,6 +2106,10 @@ int ebo_timer_begin(ebo_ctx* c)
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	return c->hip(hipEventRecord(c->ev0, c->stream), "hipEventRecord");
 }
 
@@ -2066,6 +2118,10 @@ int ebo_timer_end(ebo_ctx* c, float* ms)
 	if (!c || !ms)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	int rc = c->hip(hipEventRecord(c->ev1, c->stream), "hipEventRecord");
 	if (rc) return rc;

@@ -94,6 +94,10 @@ int ebo_comm_init(ebo_ctx* c, const ebo_comm_id* id, int rank, int nranks)
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!id || nranks <= 0 || rank < 0 || rank >= nranks)
 	{
 		return c->fail(EBO_ERR_ARG, "bad communicator arguments");
@@ -125,6 +129,10 @@ int ebo_allgather_device(ebo_ctx* c, const double* d_send, double* d_recv, size_
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!c->comm)
 	{
@@ -166,6 +174,10 @@ int ebo_reduce_sum_device(ebo_ctx* c, const double* d_send, double* d_recv, size
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!c->comm)
 	{
@@ -233,6 +245,10 @@ int ebo_allgather_track_counts(ebo_ctx* c, size_t n_local, size_t* n_all, size_t
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!c->comm)
 	{
 		return c->fail(EBO_ERR_STATE, "no communicator: call ebo_comm_init first");
@@ -270,6 +286,10 @@ int ebo_allgather_tracks(ebo_ctx* c, const ebo_track_point* local, size_t n_loca
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!c->comm)
 	{
@@ -357,6 +377,10 @@ int ebo_comm_destroy(ebo_ctx* c)
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (c->comm)
 	{

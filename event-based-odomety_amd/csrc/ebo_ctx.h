@@ -54,6 +54,7 @@ struct ebo_ctx
 	int npx = 0, npy = 0, P = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
+	bool capturing = false;  // between ebo_graph_begin and ebo_graph_end
 	std::string err;
 
 	size_t cap_events = 0;
@@ -163,6 +164,12 @@ struct ebo_ctx
 		return EBO_ERR_HIP;
 	}
 };
+
+// Between ebo_graph_begin and ebo_graph_end only the asynchronous *_device calls may run: anything that copies
+// through pageable memory, allocates or synchronises invalidates the recording -- and on ROCm 7.2 leaves the
+// process unable to use the stream again -- so every other entry point refuses up front.
+static const char* const kNotWhileRecording =
+	"not while recording a graph (ebo_graph_begin): only ebo_eval_device, ebo_solve_device and ebo_count_image_device can be recorded";
 
 // helpers defined in ebo_api.cpp and shared by the other host translation units
 namespace ebo_host

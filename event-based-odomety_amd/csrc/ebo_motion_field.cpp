@@ -15,6 +15,10 @@ int ebo_init_motion_field(ebo_ctx* c, int64_t timestamp, int use_average, int n_
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (n_patches < 0 || (n_patches > 0 && (!traj_offsets || !traj_xy || !traj_t)))
 	{
 		return c->fail(EBO_ERR_ARG, "null trajectory arrays");
@@ -118,6 +122,10 @@ int ebo_interpolate_motion_field(ebo_ctx* c, int use_l1, const ebo_solver_opts* 
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!c->field_valid)
 	{

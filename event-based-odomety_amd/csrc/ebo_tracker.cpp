@@ -16,6 +16,10 @@ static int patch_integrate_common(ebo_ctx* c, const ebo_event* ev, const size_t*
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!ev || !offsets || n_patches <= 0 || !rects || !nabla_offsets || !nabla)
 	{
 		return c->fail(EBO_ERR_ARG, "null argument to patch integrate");
@@ -158,6 +162,10 @@ int ebo_route_set_events(ebo_ctx* c, const ebo_event* ev, size_t n)
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if ((!ev && n > 0) || n > 0x7FFFFFFFu)  // k_route's 32-bit indices step by 256: no wrap-around
 	{
 		return c->fail(EBO_ERR_ARG, "null events or more than 2^31 events in a chunk");
@@ -203,6 +211,10 @@ int ebo_route_events(ebo_ctx* c, int n_patches, const double* rects, const uint3
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (n_patches < 0 || (n_patches > 0 && (!rects || !start || !max_take || !out_count || !out_next)) ||
 		(cap > 0 && n_patches > 0 && !out_index))
@@ -310,6 +322,10 @@ int ebo_optimizer_set_grad(ebo_ctx* c, const double* grad_x, const double* grad_
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!grad_x || !grad_y)
 	{
 		return c->fail(EBO_ERR_ARG, "null gradient image");
@@ -356,6 +372,10 @@ int ebo_estimate_num_events(ebo_ctx* c, int n, const double* rects, const double
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (n < 0 || (n && (!rects || !poses || !flow_dirs || !out)))
 	{
@@ -412,6 +432,10 @@ int ebo_patch_warp_image(ebo_ctx* c, int n, const double* rects, const double* p
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (n < 0 || (n && (!rects || !poses || !flow_dirs || !nabla_offsets || !predicted || !updated)))
 	{
@@ -647,6 +671,10 @@ int ebo_optimizer_eval(ebo_ctx* c, int n, const double* rects, const double* nab
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!residuals || ((jac_pose == nullptr) != (jac_flow == nullptr)))
 	{
 		return c->fail(EBO_ERR_ARG, "residuals are required; the two Jacobians come together");
@@ -684,6 +712,10 @@ int ebo_optimizer_solve(ebo_ctx* c, int n, const double* rects, const double* na
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	ebo_solver_opts o;
 	if (opts)

@@ -274,6 +274,10 @@ int ebo_set_windows_device(ebo_ctx* c, const ebo_event* d_ev, const size_t* offs
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	if (!d_ev || !offsets || n_windows <= 0)
 	{
 		return c->fail(EBO_ERR_ARG, "null events/offsets or no window");
@@ -302,6 +306,10 @@ int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int 
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!offsets || n_windows <= 0 || (!ev && offsets[n_windows] > offsets[0]))
 	{
@@ -389,6 +397,10 @@ int ebo_set_windows8_device(ebo_ctx* c, const ebo_event8* d_ev, const int64_t* t
 	{
 		return EBO_ERR_ARG;
 	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
 	int rc = check_windows8(c, d_ev, t_base, offsets, n_windows);
 	if (rc)
 	{
@@ -402,6 +414,10 @@ int ebo_set_windows8(ebo_ctx* c, const ebo_event8* ev, const int64_t* t_base, co
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	int rc = check_windows8(c, ev, t_base, offsets, n_windows);
 	if (rc)
@@ -618,6 +634,10 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 	if (!c)
 	{
 		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
 	}
 	if (!ev || !offsets || !rects || n_patches <= 0)
 	{

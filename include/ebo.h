@@ -146,6 +146,23 @@ int ebo_create(const ebo_params* p, ebo_ctx** out);
 void ebo_destroy(ebo_ctx* ctx);
 /* Launch on this HIP stream (hipStream_t) instead of the context's own. */
 int ebo_set_stream(ebo_ctx* ctx, void* hip_stream);
+/* ---- HIP graphs over the asynchronous *_device calls ------------------------------------------
+ * ebo_graph_begin starts recording the context's stream (hipStreamBeginCapture, thread-local mode);
+ * the *_device calls made until ebo_graph_end (ebo_eval_device, ebo_solve_device,
+ * ebo_count_image_device, ...) are recorded instead of run; ebo_graph_end instantiates the graph.
+ * ebo_graph_launch replays it `times` times back to back on the context's stream, asynchronously,
+ * with no host work between the steps.  Recorded calls must not allocate or synchronise: run the
+ * same sequence once before recording (work tables are allocated on first use).  The graph reads
+ * and writes the device pointers it was recorded with; ebo_set_windows / ebo_set_patches with the
+ * same sizes reuse the same buffers, other changes need a new recording.  ebo_graph_end always
+ * ends the recording, also after a failed call (EBO_ERR_HIP then, no graph).  Not in the reference:
+ * the CPU path has no launch cost to hide. */
+typedef struct ebo_graph ebo_graph;
+int ebo_graph_begin(ebo_ctx* ctx);
+int ebo_graph_end(ebo_ctx* ctx, ebo_graph** out);
+int ebo_graph_launch(ebo_ctx* ctx, ebo_graph* graph, int times);
+void ebo_graph_destroy(ebo_graph* graph);
+
 int ebo_synchronize(ebo_ctx* ctx);
 
 /* Patch grid of R2 (:301-346): npx*npy patches, last row/column absorb the remainder. */

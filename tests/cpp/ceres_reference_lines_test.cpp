@@ -24,6 +24,7 @@
 #include <vector>
 
 #include <feature_tracker/contrast_functor.h>
+#include <feature_tracker/feature_detector.h>
 #include <feature_tracker/total_variance.h>
 
 #include "../../event-based-odomety_amd/csrc/host_lm.h"

@@ -535,7 +535,7 @@ def test_central_difference_rounds_never_take_the_window_list(ebo, synth, monkey
     slots): in the pipelined driver (41 windows, two halves in flight) the solve equals, bit for bit, the
     list-free and the unpipelined one."""
     n = 41
-    ev, offsets, _ = synth.make_stream(0, n, n_events=4000)
+    ev, offsets, _ = synth.make_stream(0, n)
     kw = dict(image_w=240, image_h=180, patch_w=20, patch_h=20, grad=ebo.GRAD_CENTRAL,
               loss=ebo.LOSS_VARIANCE if loss == "variance" else ebo.LOSS_EDGE, max_events=len(ev), max_windows=n)
     out = []
@@ -547,7 +547,7 @@ def test_central_difference_rounds_never_take_the_window_list(ebo, synth, monkey
         with ebo.Context(**kw) as c:
             c.set_windows(ev, offsets)
             opts = ebo.default_solver()
-            opts.max_num_iterations = 10
+            opts.max_num_iterations = 30
             flows, summ = c.solve(opts)
             out.append((flows.copy(), [(s.iterations, s.final_cost, s.termination, s.num_evals_cost, s.num_evals_jac) for s in summ]))
     for k in ("EBO_SOLVE_NO_COMPACT", "EBO_SOLVE_NO_PIPELINE"):
