@@ -258,6 +258,25 @@ def shard_range(n_units, rank, world):
     return b.value, e.value
 
 
+class Band(C.Structure):
+    """ebo_band: one rank's share of the final image of row-sharded windows."""
+    _fields_ = [("band_row0", C.c_int), ("own_row0", C.c_int), ("own_row1", C.c_int), ("band_row1", C.c_int),
+                ("recv_above", C.c_int), ("recv_below", C.c_int)]
+
+    top_rows = property(lambda s: s.own_row0 - s.band_row0)
+    own_rows = property(lambda s: s.own_row1 - s.own_row0)
+    bottom_rows = property(lambda s: s.band_row1 - s.own_row1)
+
+
+def band_plan(image_h, row_bounds, rank, halo):
+    rb = np.ascontiguousarray(row_bounds, dtype=np.int32)
+    out = Band()
+    rc = lib().ebo_band_plan(int(image_h), rb.ctypes.data_as(C.c_void_p), len(rb) - 1, int(rank), int(halo), C.byref(out))
+    if rc:
+        raise EboError(rc, "no band plan: bad row bounds, or a halo that does not fit inside a neighbour's rows")
+    return out
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -766,16 +785,52 @@ class Context:
             int(root)))
 
     def allgather_tracks(self, local):
-        """Every rank's track records on every rank (rank order): -> (records, counts per rank).  The counts
-        collective sizes the result (its array from the communicator's own size), the gather fills it."""
+        """Every rank's track records on every rank (rank order): -> (records, counts per rank).  ONE counts
+        collective + ONE gather per call: the result buffer is kept between calls and grows by a rule that
+        depends only on the gathered total (4096 records, then the next power of two), so every rank finds it
+        too small -- and repeats the exchange -- in the same call."""
         local = np.ascontiguousarray(local, dtype=TRACK_DTYPE)
         nr = C.c_size_t()
         counts = np.zeros(self.comm_size()[1], dtype=np.uint64)
-        self._check(lib().ebo_allgather_track_counts(self._h, C.c_size_t(len(local)), C.byref(nr), _vp(counts)))
-        out = np.zeros(nr.value, dtype=TRACK_DTYPE)
-        self._check(lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), _vp(out) if len(out) else None,
-                                               C.c_size_t(len(out)), C.byref(nr), _vp(counts)))
-        return out, counts.astype(np.int64)
+        buf = getattr(self, "_track_buf", None)
+        if buf is None:
+            buf = self._track_buf = np.zeros(4096, dtype=TRACK_DTYPE)
+        rc = lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), _vp(buf), C.c_size_t(len(buf)),
+                                        C.byref(nr), _vp(counts))
+        if rc == ERR_ARG and nr.value > len(buf):  # the same on every rank: all of them repeat
+            buf = self._track_buf = np.zeros(1 << int(nr.value - 1).bit_length(), dtype=TRACK_DTYPE)
+            rc = lib().ebo_allgather_tracks(self._h, _vp(local), C.c_size_t(len(local)), _vp(buf), C.c_size_t(len(buf)),
+                                            C.byref(nr), _vp(counts))
+        self._check(rc)
+        return buf[:nr.value].copy(), counts.astype(np.int64)
+
+    # -- band-limited final image of row-sharded windows (SURVEY 8(e)) -------------------------
+    def band_plan(self, row_bounds, rank, halo):
+        """-> Band for `rank` of the partition row_bounds [nranks + 1] (image rows); EboError(ERR_UNSUPPORTED) when a
+        halo would not fit inside a neighbour's rows."""
+        return band_plan(self.params.image_h, row_bounds, rank, halo)
+
+    def count_image_band_device(self, n_windows, t_ref_us, d_flows_grid, band, d_top, d_own, d_bottom, d_escaped):
+        t_ref = np.ascontiguousarray(t_ref_us, dtype=np.int64).reshape(n_windows)
+        self._check(lib().ebo_count_image_band_device(
+            self._h, int(n_windows), _vp(t_ref), C.c_void_p(int(d_flows_grid)), C.byref(band),
+            C.c_void_p(int(d_top)) if d_top else None, C.c_void_p(int(d_own)) if d_own else None,
+            C.c_void_p(int(d_bottom)) if d_bottom else None, C.c_void_p(int(d_escaped))))
+
+    def band_exchange_device(self, n_windows, band, d_top, d_bottom, d_from_above, d_from_below, d_escaped):
+        p = lambda v: C.c_void_p(int(v)) if v else None
+        self._check(lib().ebo_band_exchange_device(self._h, int(n_windows), C.byref(band), p(d_top), p(d_bottom),
+                                                   p(d_from_above), p(d_from_below), p(d_escaped)))
+
+    def band_finish_device(self, n_windows, band, d_own, d_from_above, d_from_below, d_image_own):
+        p = lambda v: C.c_void_p(int(v)) if v else None
+        self._check(lib().ebo_band_finish_device(self._h, int(n_windows), C.byref(band), p(d_own), p(d_from_above),
+                                                 p(d_from_below), p(d_image_own)))
+
+    def band_gather_device(self, n_windows, row_bounds, d_image_own, root, d_full):
+        rb = np.ascontiguousarray(row_bounds, dtype=np.int32)
+        self._check(lib().ebo_band_gather_device(self._h, int(n_windows), _vp(rb), C.c_void_p(int(d_image_own)) if d_image_own else None,
+                                                 int(root), C.c_void_p(int(d_full)) if d_full else None))
 
     def comm_destroy(self):
         self._check(lib().ebo_comm_destroy(self._h))

@@ -1477,6 +1477,7 @@ void ebo_destroy(ebo_ctx* c)
 	}
 	(void)ebo_comm_destroy(c);
 	hipFree(c->d_events);
+	hipFree(c->d_shard_tbl);
 	hipFree(c->d_units);
 	hipFree(c->d_unit_maxdt);
 	hipFree(c->d_flows);
@@ -1974,56 +1975,23 @@ int ebo_count_image_shard_device(ebo_ctx* c, int n_windows, const int64_t* windo
 	{
 		return c->fail(EBO_ERR_ARG, "bad argument to ebo_count_image_shard");
 	}
-	if (!c->custom_n)
-	{
-		return c->fail(EBO_ERR_STATE, "ebo_count_image_shard needs the units of a shard (ebo_set_patches)");
-	}
-	if (c->custom_n % n_windows != 0)
-	{
-		return c->fail(EBO_ERR_ARG, "the loaded units are not n_windows equal groups");
-	}
 	(void)hipSetDevice(c->prm.device);
+	// the per-unit times against the windows' reference times: built once per set of windows, kept on the device
+	const BandUnit* tbl = nullptr;
+	int rc = shard_table(c, n_windows, window_t_ref_us, &tbl, nullptr);
+	if (rc)
+	{
+		return rc;
+	}
 	const int per = c->custom_n / n_windows;
-	// dt of an event against the WINDOW's reference time = dt against the unit's + dtWin: both int32
-	std::vector<int32_t> dtw(static_cast<size_t>(c->custom_n), 0);
-	for (int k = 0; k < c->custom_n; ++k)
-	{
-		if (c->units[k].n_ev == 0)
-		{
-			continue;
-		}
-		const int64_t tw = window_t_ref_us[k / per];
-		const int64_t d = tw - c->unit_tref[k];
-		if (d < INT32_MIN || d > INT32_MAX || tw - c->unit_tmin[k] > INT32_MAX || tw - c->unit_tmax[k] < INT32_MIN)
-		{
-			return c->fail(EBO_ERR_RANGE, "window reference time further than 2^31 us from a unit's events");
-		}
-		dtw[k] = static_cast<int32_t>(d);
-	}
-	int rc = ensure_aux(c, dtw.size() * sizeof(int32_t));
+	rc = c->hip(hipMemsetAsync(d_image, 0, static_cast<size_t>(n_windows) * c->prm.image_w * c->prm.image_h * sizeof(double),
+							   c->stream),
+				"zero shard image");
 	if (rc)
 	{
 		return rc;
 	}
-	rc = c->hip(hipMemcpyAsync(c->d_aux, dtw.data(), dtw.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream),
-				"H2D shard time offsets");
-	if (rc == EBO_OK)
-	{
-		// dtw is a local: the copy must have left host memory before it goes out of scope
-		rc = c->hip(hipStreamSynchronize(c->stream), "sync");
-	}
-	if (rc == EBO_OK)
-	{
-		rc = c->hip(hipMemsetAsync(d_image, 0, static_cast<size_t>(n_windows) * c->prm.image_w * c->prm.image_h * sizeof(double),
-								   c->stream),
-					"zero shard image");
-	}
-	if (rc)
-	{
-		return rc;
-	}
-	if (launch_count_shard(c->d_events, c->d_units, c->custom_n, per, static_cast<const int32_t*>(c->d_aux), d_flows_grid,
-						   d_image, make_consts(c), c->stream))
+	if (launch_count_shard(c->d_events, c->d_units, c->custom_n, per, tbl, d_flows_grid, d_image, make_consts(c), c->stream))
 	{
 		return c->fail(EBO_ERR_HIP, "k_count_shard launch failed");
 	}

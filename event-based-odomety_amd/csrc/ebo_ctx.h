@@ -103,6 +103,10 @@ struct ebo_ctx
 	size_t tvf_cap = 0;
 	void* comm = nullptr;            // ncclComm_t of ebo_comm_init
 	int comm_rank = 0, comm_size = 1;
+	uint64_t* d_comm_cnt = nullptr;  // [nranks + 2] counts / flags of the exchange (allocated by ebo_comm_init)
+	uint64_t* pin_comm = nullptr;    // the same, pinned host side
+	void* d_comm_buf = nullptr;      // track exchange buffer; grown collectively (ebo_comm.cpp: ensure_comm_buf)
+	size_t comm_buf_cap = 0;
 	void* d_raw = nullptr;           // raw 24-byte (or compact 8-byte) events staged for device bucketing
 	hipStream_t copy_stream = nullptr;  // uploads of ebo_set_windows / ebo_set_windows8, overlapped with the bucketing
 	hipEvent_t copy_done[8] = {};
@@ -114,6 +118,14 @@ struct ebo_ctx
 	std::vector<Unit> units;       // [Wn][P+1], stray unit last in each window
 	std::vector<int64_t> unit_tref;
 	std::vector<int64_t> unit_tmin, unit_tmax;  // ebo_set_patches: earliest / latest event time per unit (ebo_count_image_shard)
+	std::vector<int16_t> unit_box;              // ebo_set_patches: [unit][4] = min x, max x, min y, max y of the unit's events
+	uint64_t units_gen = 0;                     // bumped by every ebo_set_*: invalidates the cached shard tables below
+	void* d_shard_tbl = nullptr;                // BandUnit[units] (band image) / int32 dt_win[units] (dense shard image)
+	size_t shard_tbl_cap = 0;
+	uint64_t shard_tbl_gen = 0;                 // units_gen the table was built for (0 = none)
+	int shard_tbl_kind = 0;                     // 1 = dt_win only, 2 = BandUnit
+	std::vector<int64_t> shard_tbl_tref;        // the windows' reference times it was built for
+	int* d_escaped_own = nullptr;               // ebo_count_image_band's own flag word
 	std::vector<WindowInfo> windows;
 	std::vector<uint64_t> h_packed;
 	// pinned, device-visible staging of one evaluation round (flows in, (r, J0, J1) out, modes):
@@ -184,4 +196,6 @@ int ensure_scratch(ebo_ctx* c, size_t bytes);
 int ensure_aux(ebo_ctx* c, size_t bytes);
 ebo::SolveConsts make_solve_consts(const ebo_solver_opts* o);
 int check_solver_opts(ebo_ctx* c, const ebo_solver_opts* o);
+int shard_table(ebo_ctx* c, int n_windows, const int64_t* window_t_ref_us, const ebo::BandUnit** out, bool* uniformFlows);
+bool band_ok(const ebo_ctx* c, const ebo_band* b);
 }  // namespace ebo_host

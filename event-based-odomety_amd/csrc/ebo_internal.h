@@ -158,8 +158,38 @@ struct EdgeLaunch
 };
 int launch_lds_rate(int atomic, int blocks, int iters, double* d_sink, void* stream);
 int launch_stream_yardstick(const uint64_t* d_events, size_t n_events, double* d_image, size_t n_pixels, void* stream);
+// what k_count_band needs of a unit of a row shard besides its Unit: times against the WINDOW's reference time,
+// the bounding box of its events (they may lie outside the rect: strays take the clamped patch) and its grid patch
+struct BandUnit
+{
+	int32_t dt_win;  // t_ref(window) - t_ref(unit)
+	int32_t max_dt;  // max |t_ref(window) - t| over the unit's events
+	int16_t x0, x1, y0, y1;  // inclusive bounding box of the unit's events
+	int32_t flow;    // grid patch whose flow the unit's events take (feature_detector.cpp:436-441)
+	int32_t reserved;
+};
+static_assert(sizeof(BandUnit) == 24, "BandUnit layout");
+
+struct BandLaunch
+{
+	const uint64_t* d_events;
+	const Unit* d_units;
+	const BandUnit* d_band_units;
+	int per;        // units per window
+	int n_windows;
+	const double* d_flows;  // [n_windows][P][2], all grid patches
+	int band0, own0, own1, band1;
+	unsigned int* d_top;
+	unsigned int* d_own;
+	unsigned int* d_bottom;
+	int* d_escaped;
+	EvalConsts c;
+};
+int launch_count_band(const BandLaunch& L, void* stream);
 int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,
-					   const int32_t* d_dtwin, const double* d_flows, double* d_image, const EvalConsts& c, void* stream);
+					   const BandUnit* d_table, const double* d_flows, double* d_image, const EvalConsts& c, void* stream);
+int launch_band_finish(const unsigned int* d_own, const unsigned int* d_from_above, const unsigned int* d_from_below,
+					   int own_rows, int recv_above, int recv_below, int W, int n_windows, double* d_image, void* stream);
 int launch_eval_edge(const EdgeLaunch& L, void* stream);
 int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows_out, int32_t* d_stats, void* stream);
 

@@ -2217,7 +2217,7 @@ __global__ void __launch_bounds__(256) k_stream_yardstick(const uint4* __restric
 // the grid patch its own coordinates select (:436-441) and adds 1.0 at its rounded warped position.
 // The partial images of the ranks are integer-valued doubles: their sum is exact in any order.
 __global__ void k_count_shard(const uint64_t* __restrict__ events, const Unit* __restrict__ units, int unitsPerWindow,
-							  const int32_t* __restrict__ dtWin, const double* __restrict__ flows,
+							  const BandUnit* __restrict__ table, const double* __restrict__ flows,
 							  double* __restrict__ image, EvalConsts c)
 {
 	const Unit un = units[blockIdx.x];
@@ -2225,7 +2225,7 @@ __global__ void k_count_shard(const uint64_t* __restrict__ events, const Unit* _
 	const int P = c.npx * c.npy;
 	const double* windowFlows = flows + 2 * static_cast<size_t>(w) * P;
 	double* img = image + static_cast<size_t>(w) * c.image_w * c.image_h;
-	const int dtw = dtWin[blockIdx.x];
+	const int dtw = table[blockIdx.x].dt_win;
 	for (uint32_t e = threadIdx.x; e < un.n_ev; e += blockDim.x)
 	{
 		const uint64_t rec = events[un.ev_off + e];
@@ -2905,6 +2905,7 @@ __global__ void __launch_bounds__(64) k_route(const uint32_t* __restrict__ xy, u
 #include "ebo_field.inc"
 #include "ebo_fieldtv.inc"
 #include "ebo_optimizer.inc"
+#include "ebo_band.inc"
 
 int check_launch()
 {
@@ -3449,15 +3450,65 @@ int launch_stream_yardstick(const uint64_t* d_events, size_t n_events, double* d
 }
 
 int launch_count_shard(const uint64_t* d_events, const Unit* d_units, int n_units, int units_per_window,
-					   const int32_t* d_dtwin, const double* d_flows, double* d_image, const EvalConsts& c, void* stream)
+					   const BandUnit* d_table, const double* d_flows, double* d_image, const EvalConsts& c, void* stream)
 {
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (n_units == 0)
 	{
 		return 0;
 	}
-	hipLaunchKernelGGL(k_count_shard, dim3(n_units), dim3(256), 0, s, d_events, d_units, units_per_window, d_dtwin,
+	hipLaunchKernelGGL(k_count_shard, dim3(n_units), dim3(256), 0, s, d_events, d_units, units_per_window, d_table,
 					   d_flows, d_image, c);
+	return check_launch();
+}
+
+int launch_count_band(const BandLaunch& L, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const int bandRows = L.band1 - L.band0;
+	if (L.n_windows <= 0 || L.per <= 0 || bandRows <= 0)
+	{
+		return 0;
+	}
+	// tiles of <= 15360 counters (60 KB) + the selection list: two workgroups per CU; about 160 columns wide, so
+	// that a tile's units are few (events are re-read once per tile their reach touches)
+	const int W = L.c.image_w;
+	const int tilesX = std::max(1, (W + 159) / 160);
+	int tw = (W + tilesX - 1) / tilesX;
+	const int thMax = std::max(1, 15360 / tw);
+	const int tilesY = (bandRows + thMax - 1) / thMax;
+	const int th = (bandRows + tilesY - 1) / tilesY;
+	BandGeom g;
+	g.band0 = L.band0;
+	g.own0 = L.own0;
+	g.own1 = L.own1;
+	g.band1 = L.band1;
+	g.tileW = tw;
+	g.tileH = th;
+	g.tilesX = tilesX;
+	g.tilesY = tilesY;
+	const size_t lds = (static_cast<size_t>(tw) * th + 1 + static_cast<size_t>(L.per)) * sizeof(int);
+	if (lds > 160 * 1024 || allow_big_lds(k_count_band, lds))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_count_band, dim3(tilesX * tilesY, L.n_windows), dim3(512), lds, s, L.d_events, L.d_units, L.d_band_units,
+					   L.per, L.d_flows, g, L.d_top, L.d_own, L.d_bottom, L.d_escaped, L.c);
+	return check_launch();
+}
+
+int launch_band_finish(const unsigned int* d_own, const unsigned int* d_from_above, const unsigned int* d_from_below,
+					   int own_rows, int recv_above, int recv_below, int W, int n_windows, double* d_image, void* stream)
+{
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	const size_t n = static_cast<size_t>(n_windows) * own_rows * W;
+	if (n == 0)
+	{
+		return 0;
+	}
+	const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 4096));
+	hipLaunchKernelGGL(k_band_finish, dim3(blocks), dim3(256), 0, s, d_own, d_from_above, d_from_below, own_rows, recv_above,
+					   recv_below, W, n, d_image);
 	return check_launch();
 }
 

@@ -250,6 +250,7 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 	}
 	(void)total;
 	c->units.swap(units);
+	++c->units_gen;
 	c->unit_tref.swap(utref);
 	c->windows.swap(wins);
 	c->n_windows = n_windows;
@@ -617,6 +618,7 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 		return rc;
 	}
 	c->units.swap(units);
+	++c->units_gen;
 	c->unit_tref.swap(utref);
 	c->windows.swap(wins);
 	c->n_windows = n_windows;
@@ -654,6 +656,7 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 	}
 	std::vector<Unit> units(n_patches);
 	std::vector<int64_t> utref(n_patches, 0), utmin(n_patches, 0), utmax(n_patches, 0);
+	std::vector<int16_t> ubox(4 * static_cast<size_t>(n_patches), 0);
 	c->h_packed.resize(total);
 	int mrw = 0, mrh = 0, lrw = 0x7fffffff, lrh = 0x7fffffff;
 	size_t base = 0;
@@ -692,10 +695,15 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 		}
 		utref[p] = tu;
 		int64_t tlo = n ? pe[0].t_us : 0, thi = tlo;
+		int32_t bx0 = n ? pe[0].x : 0, bx1 = bx0, by0 = n ? pe[0].y : 0, by1 = by0;
 		for (size_t i = 0; i < n; ++i)
 		{
 			tlo = std::min<int64_t>(tlo, pe[i].t_us);
 			thi = std::max<int64_t>(thi, pe[i].t_us);
+			bx0 = std::min(bx0, pe[i].x);
+			bx1 = std::max(bx1, pe[i].x);
+			by0 = std::min(by0, pe[i].y);
+			by1 = std::max(by1, pe[i].y);
 			if (pe[i].x < kCoordMin || pe[i].x > kCoordMax || pe[i].y < kCoordMin || pe[i].y > kCoordMax)
 			{
 				return c->fail(EBO_ERR_RANGE, "event coordinate outside [-16384,16383]");
@@ -719,6 +727,11 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 		}
 		utmin[p] = tlo;
 		utmax[p] = thi;
+		// (coordinates were range-checked above: they fit int16)
+		ubox[4 * static_cast<size_t>(p) + 0] = static_cast<int16_t>(bx0);
+		ubox[4 * static_cast<size_t>(p) + 1] = static_cast<int16_t>(bx1);
+		ubox[4 * static_cast<size_t>(p) + 2] = static_cast<int16_t>(by0);
+		ubox[4 * static_cast<size_t>(p) + 3] = static_cast<int16_t>(by1);
 		base += n;
 	}
 	(void)hipSetDevice(c->prm.device);
@@ -749,6 +762,8 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 	c->unit_tref.swap(utref);
 	c->unit_tmin.swap(utmin);
 	c->unit_tmax.swap(utmax);
+	c->unit_box.swap(ubox);
+	++c->units_gen;
 	c->windows.assign(1, WindowInfo{0, total});
 	c->n_windows = 1;
 	c->custom_n = n_patches;

@@ -418,6 +418,44 @@ int ebo_count_image_shard(ebo_ctx* ctx, int n_windows, const int64_t* window_t_r
 int ebo_count_image_shard_device(ebo_ctx* ctx, int n_windows, const int64_t* window_t_ref_us,
 								 const double* d_flows_grid, double* d_image);
 
+/* The same image BAND-LIMITED ("each GPU writes its own row-block; events warped across a
+ * shard border need a halo"): a rank's events start in the image rows of its patch rows [own_row0,
+ * own_row1) and leave them only by max|dt| * scale * |flow|, so the rank counts them into a band = its own
+ * rows + `halo` rows above and below (clipped to the image), keeps the own rows and sends only the halo
+ * rows to the two neighbouring ranks -- instead of reducing a full image per window from every rank onto one.
+ *   ebo_band_plan            host only.  row_bounds [nranks + 1]: rank q owns image rows [row_bounds[q],
+ *                            row_bounds[q + 1]) (0 ... image_h, rank order = row order).  Fills *out for `rank`.
+ *                            EBO_ERR_UNSUPPORTED when some rank's halo would not fit inside its neighbour's rows
+ *                            (the same verdict on every rank: all decide from the same numbers).
+ *   ebo_count_image_band_device   counts this context's events (ebo_set_patches, as for ebo_count_image_shard)
+ *                            into d_top [n_windows][own_row0 - band_row0][W], d_own [n_windows][own rows][W],
+ *                            d_bottom [n_windows][band_row1 - own_row1][W] (uint32 counts; LDS tiles, no global
+ *                            atomics).  *d_escaped (int32, device) becomes 1 when a unit's flow could carry an event
+ *                            to an image row outside the band (then the caller falls back to
+ *                            ebo_count_image_shard + reduce), else 0.  EBO_ERR_UNSUPPORTED when a unit's events select
+ *                            more than one grid patch (arbitrary rects: use ebo_count_image_shard).  Asynchronous.
+ *   ebo_band_exchange_device (ebo_comm_init) d_top -> rank - 1, d_bottom -> rank + 1, the neighbours' halos into
+ *                            d_from_above [n_windows][recv_above][W] and d_from_below [n_windows][recv_below][W]
+ *                            (one grouped ncclSend / ncclRecv), then *d_escaped = max over the ranks (ncclAllReduce of
+ *                            one int): every rank takes the same fallback decision.  Without a communicator: no-op.
+ *   ebo_band_finish_device   d_image_own [n_windows][own rows][W] (CV_64F) = own + received halos.
+ *   ebo_band_gather_device   (ebo_comm_init) only when one rank wants the whole image: every rank's d_image_own into
+ *                            d_full [n_windows][image_h][W] on `root` (grouped send / recv of the owned rows only).
+ * Bytes a rank sends per window: (rows of top + rows of bottom) x W x 4. */
+typedef struct ebo_band
+{
+	int band_row0, own_row0, own_row1, band_row1; /* image rows: band = [band_row0, band_row1), own inside it */
+	int recv_above, recv_below;                   /* rows of the own region the neighbours' halos cover */
+} ebo_band;
+int ebo_band_plan(int image_h, const int* row_bounds, int nranks, int rank, int halo, ebo_band* out);
+int ebo_count_image_band_device(ebo_ctx* ctx, int n_windows, const int64_t* window_t_ref_us, const double* d_flows_grid,
+								const ebo_band* band, uint32_t* d_top, uint32_t* d_own, uint32_t* d_bottom, int32_t* d_escaped);
+int ebo_band_exchange_device(ebo_ctx* ctx, int n_windows, const ebo_band* band, const uint32_t* d_top, const uint32_t* d_bottom,
+							 uint32_t* d_from_above, uint32_t* d_from_below, int32_t* d_escaped);
+int ebo_band_finish_device(ebo_ctx* ctx, int n_windows, const ebo_band* band, const uint32_t* d_own, const uint32_t* d_from_above,
+						   const uint32_t* d_from_below, double* d_image_own);
+int ebo_band_gather_device(ebo_ctx* ctx, int n_windows, const int* row_bounds, const double* d_image_own, int root, double* d_full);
+
 /* R2 in one call: set window, solve, final warped count image.
  * flows_out [P][2], image_out [image_h][image_w] (may be NULL). */
 int ebo_compensate_events_contrast(ebo_ctx* ctx, const ebo_event* ev, size_t n,

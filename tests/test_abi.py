@@ -103,3 +103,17 @@ def test_synthetic_generator_is_deterministic(synth):
     assert [int(v) for v in z] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
     npx, npy, rects = synth.grid_rects((240, 180), (30, 22))
     assert (npx, npy) == (8, 8) and tuple(rects[-1]) == (210, 154, 30, 26)
+
+
+def test_band_plan_rows(ebo):
+    """Host only: the plan of every rank from the same row bounds."""
+    b = ebo.band_plan(720, [0, 88, 176, 264, 720], 1, 32)
+    assert (b.band_row0, b.own_row0, b.own_row1, b.band_row1, b.recv_above, b.recv_below) == (56, 88, 176, 208, 32, 32)
+    b = ebo.band_plan(720, [0, 88, 176, 264, 720], 0, 32)
+    assert (b.band_row0, b.own_row0, b.own_row1, b.band_row1, b.recv_above, b.recv_below) == (0, 0, 88, 120, 0, 32)
+    b = ebo.band_plan(720, [0, 88, 176, 264, 720], 3, 32)
+    assert (b.band_row0, b.band_row1, b.recv_above, b.recv_below) == (232, 720, 32, 0)
+    b = ebo.band_plan(180, [0, 180], 0, 50)  # one rank: the band is the image
+    assert (b.band_row0, b.band_row1, b.recv_above, b.recv_below) == (0, 180, 0, 0)
+    with pytest.raises(ebo.EboError):
+        ebo.band_plan(180, [0, 100, 170], 0, 5)  # bounds do not end at the image height

@@ -124,3 +124,129 @@ def test_count_image_shard_argument_errors(ebo, synth):
         with pytest.raises(ebo.EboError) as err:  # reference time 2^31 us away from the events
             c.count_image_shard(1, [int(ev["t_us"][0]) + (1 << 32)], np.zeros((1, c.P, 2)))
         assert err.value.code == ebo.ERR_RANGE
+
+
+def _band_setup(ebo, synth, config, world, n_windows, stray, flow_amp, seed):
+    cfg = synth.CONFIGS[config]
+    iw, ih = cfg["image"]
+    pw, ph = cfg["patch"]
+    rng = np.random.default_rng(seed)
+    evs, offs = [], [0]
+    for w in range(n_windows):
+        ev, _ = synth.make_window(config, window=w, n_events=min(cfg["events"], 120000))
+        if stray:
+            k = rng.choice(len(ev), stray, replace=False)
+            ev = ev.copy()
+            ev["x"][k[: stray // 2]] = rng.integers(-30, 0, stray // 2)
+            ev["y"][k[stray // 2:]] = ih + rng.integers(0, 30, stray - stray // 2)
+        evs.append(ev)
+        offs.append(offs[-1] + len(ev))
+    allev = np.concatenate(evs)
+    kw = dict(image_w=iw, image_h=ih, patch_w=pw, patch_h=ph, loss=ebo.LOSS_VARIANCE, tv_weight=0.0,
+              max_events=len(allev), max_windows=n_windows)
+    with ebo.Context(**kw) as c:
+        c.set_windows(allev, offs)
+        npx, npy, P = c.npx, c.npy, c.P
+        flows = rng.uniform(-flow_amp, flow_amp, (n_windows, P, 2))
+        whole = c.count_image(ebo.COUNT_WARPED, flows)
+        rects = np.array([c.patch_rect(p % npx, p // npx) for p in range(P)])
+        t_ref = [c.window_info(w)[0] for w in range(n_windows)]
+    return dict(cfg=cfg, evs=evs, kw=kw, npx=npx, npy=npy, P=P, flows=flows, whole=whole, rects=rects, t_ref=t_ref,
+                iw=iw, ih=ih, pw=pw, ph=ph)
+
+
+def _shard_events(S, b, e, n_windows):
+    npx, npy, pw, ph = S["npx"], S["npy"], S["pw"], S["ph"]
+    my = np.arange(b * npx, e * npx)
+    sev, soffs = [], [0]
+    for w in range(n_windows):
+        ev = S["evs"][w]
+        gx = np.clip(np.trunc(ev["x"] / pw).astype(np.int64), 0, npx - 1)
+        gy = np.clip(np.trunc(ev["y"] / ph).astype(np.int64), 0, npy - 1)
+        pid = gy * npx + gx
+        for p in my:
+            sel = ev[pid == p]
+            sev.append(sel)
+            soffs.append(soffs[-1] + len(sel))
+    return my, np.concatenate(sev), soffs
+
+
+@pytest.mark.parametrize("config,world,n_windows,stray,flow_amp,halo,expect_escape", [
+    (0, 2, 2, 0, 0.6, 20, False),     # reference grid, two ranks, reach <= 0.6 * 26 + 1 < 20 rows
+    (2, 3, 1, 40, 0.5, 16, False),    # C2 with events outside the sensor (they live on the border patches' ranks)
+    (3, 8, 2, 25, 0.9, 28, False),    # C3 over 8 ranks: 2 grid rows = 32 image rows per rank, halo 28
+    (4, 8, 1, 0, 1.0, 32, False),     # C4 as the bench shards it: 90 rows per rank, halo 32
+    (3, 8, 1, 0, 6.0, 28, True),      # +-150 px: far beyond any halo -> every rank reports it, the dense path answers
+    (4, 3, 1, 0, 1.0, 400, None),     # a halo larger than a rank's rows: no plan (ERR_UNSUPPORTED on every rank)
+])
+def test_band_limited_images_of_the_shards_assemble_the_whole_image(ebo, synth, config, world, n_windows, stray, flow_amp,
+                                                                     halo, expect_escape):
+    """SURVEY 8(e)'s band-limited final image: every rank counts its events into its own rows + a halo (LDS tiles, no
+    global atomics), the halo rows go to the two neighbours, own + received halos = the rank's rows of the one-process
+    image, bit for bit.  The exchange is done here by handing the buffers over in one process (what
+    ebo_band_exchange_device's send / recv do between ranks).  Flows beyond the halo raise the flag on a rank that
+    could lose events; then the dense path (ebo_count_image_shard + sum) is the answer."""
+    import torch
+    S = _band_setup(ebo, synth, config, world, n_windows, stray, flow_amp, 23 + config)
+    iw, ih, npy, ph = S["iw"], S["ih"], S["npy"], S["ph"]
+    bounds = [ebo.shard_range(npy, r, world)[0] * ph for r in range(world)] + [ih]
+    if expect_escape is None:
+        for r in range(world):
+            with pytest.raises(ebo.EboError) as err:
+                ebo.band_plan(ih, bounds, r, halo)
+            assert err.value.code == ebo.ERR_UNSUPPORTED
+        return
+    d_flows = torch.from_numpy(S["flows"]).to("cuda")
+    ranks = []
+    for r in range(world):
+        b, e = ebo.shard_range(npy, r, world)
+        band = ebo.band_plan(ih, bounds, r, halo)
+        assert (band.own_row0, band.own_row1) == (bounds[r], bounds[r + 1])
+        R = dict(band=band, ctx=None)
+        mk = lambda rows: torch.full((n_windows, rows, iw), -7, dtype=torch.int32, device="cuda") if rows else None
+        R["top"], R["own"], R["bottom"] = mk(band.top_rows), mk(band.own_rows), mk(band.bottom_rows)
+        R["flag"] = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        if b < e:
+            my, sev, soffs = _shard_events(S, b, e, n_windows)
+            c = ebo.Context(**S["kw"])
+            c.set_patches(sev, soffs, np.tile(S["rects"][my], (n_windows, 1)))
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            c.count_image_band_device(n_windows, S["t_ref"], d_flows.data_ptr(), band, ptr(R["top"]), ptr(R["own"]),
+                                      ptr(R["bottom"]), R["flag"].data_ptr())
+            c.synchronize()
+            R["ctx"] = c
+        else:
+            R["flag"].zero_()
+        ranks.append(R)
+    torch.cuda.synchronize()
+    escaped = max(int(R["flag"].item()) for R in ranks)  # ebo_band_exchange_device: ncclAllReduce(max)
+    assert escaped == (1 if expect_escape else 0)
+    if not escaped:
+        rows, sent = [], 0
+        for r, R in enumerate(ranks):
+            band = R["band"]
+            above = ranks[r - 1]["bottom"] if r > 0 else None        # what rank r - 1 sends down
+            below = ranks[r + 1]["top"] if r + 1 < world else None   # what rank r + 1 sends up
+            assert (above.shape[1] if above is not None else 0) == band.recv_above
+            assert (below.shape[1] if below is not None else 0) == band.recv_below
+            sent = max(sent, (band.top_rows + band.bottom_rows) * iw * 4)
+            if R["ctx"] is None:
+                continue
+            img = torch.zeros((n_windows, band.own_rows, iw), dtype=torch.float64, device="cuda")
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            R["ctx"].band_finish_device(n_windows, band, ptr(R["own"]), ptr(above), ptr(below), img.data_ptr())
+            R["ctx"].synchronize()
+            rows.append(img.cpu().numpy())
+        full = np.concatenate(rows, axis=1)
+        assert np.array_equal(full, S["whole"])
+        assert sent <= 0.25 * ih * iw * 8 or world < 8  # bytes a rank sends per window against the dense f64 image
+    else:
+        total = np.zeros_like(S["whole"])
+        for R in ranks:
+            if R["ctx"] is not None:
+                total += R["ctx"].count_image_shard(n_windows, S["t_ref"], S["flows"])
+        assert np.array_equal(total, S["whole"])
+    for R in ranks:
+        if R["ctx"] is not None:
+            R["ctx"].close()
+    assert S["whole"].sum() > 0.5 * sum(len(e) for e in S["evs"])
