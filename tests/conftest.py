@@ -4,6 +4,15 @@ import sys
 
 import pytest
 
+# PyTorch (test plumbing for device buffers) bundles its own libamdhip64.so.  Whichever HIP runtime a process
+# loads first answers to that SONAME from then on: load torch's BEFORE the product library pulls in /opt/rocm's, or a
+# later `import torch` finds the other runtime under its name and reports "No HIP GPUs are available".  (The product
+# itself never needs torch; bench.py imports torch first for the same reason.)
+try:
+    import torch  # noqa: F401
+except Exception:  # a CPU-only environment without torch: the tests that need it import it themselves
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
