@@ -211,9 +211,9 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-class Comm:
-    """The collectives of one run: RCCL ("nccl") on device tensors, or — rehearsal only — gloo on
-    host copies.  world == 1 without EBO_BENCH_FORCE_DIST: no process group at all."""
+class TorchComm:
+    """The collectives of one run over torch.distributed: RCCL ("nccl") on device tensors, or -- rehearsal only --
+    gloo on host copies.  world == 1 without EBO_BENCH_FORCE_DIST: no process group at all."""
 
     def __init__(self, torch, rank, world, local, rehearse, force):
         self.torch, self.rank, self.world = torch, rank, world
@@ -229,6 +229,11 @@ class Comm:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        self.transport = "none (one rank)" if not self.active else (
+            "torch.distributed over %s" % ("RCCL" if self.backend == "nccl" else self.backend))
+
+    def attach(self, ctx):
+        pass
 
     @property
     def coll_device(self):
@@ -279,7 +284,22 @@ class Comm:
             t_dev.copy_(staging)
         return t_dev
 
-    def allgather_tracks(self, exchange, local):
+    def halo_exchange(self, exchange, ctx, n_windows, band, B):
+        """top -> rank - 1, bottom -> rank + 1, the neighbours' halos in, the flag = max over ranks"""
+        if not self.active:
+            return
+        if self.backend == "gloo":
+            host = {k: (B[k].cpu() if B[k] is not None else None) for k in ("top", "bottom", "from_above", "from_below")}
+            flag = B["flag"].cpu()
+            exchange.halo_exchange(host["top"], host["bottom"], host["from_above"], host["from_below"], flag)
+            for k in ("from_above", "from_below"):
+                if B[k] is not None:
+                    B[k].copy_(host[k])
+            B["flag"].copy_(flag)
+            return
+        exchange.halo_exchange(B["top"], B["bottom"], B["from_above"], B["from_below"], B["flag"])
+
+    def allgather_tracks(self, exchange, ctx, local):
         if not self.active:
             return local, [len(local)]
         return exchange.allgather_tracks(local, device=self.coll_device)
@@ -287,6 +307,79 @@ class Comm:
     def close(self):
         if self.active:
             self.dist.destroy_process_group()
+
+
+class EboComm:
+    """The same collectives on the LIBRARY's own communicator (csrc/ebo_comm.cpp: librccl.so dlopened, no
+    framework): rank 0 makes the id (ebo_comm_unique_id), hands its 128 bytes over through a file
+    (exchange.handover_bytes), every rank calls ebo_comm_init on the workload's context; barrier and reductions are
+    ebo_allgather_device of one double per rank, the flows go through ebo_allgather_device, the halos through
+    ebo_band_exchange_device, the tracks through ebo_allgather_tracks."""
+
+    def __init__(self, torch, ebo, exchange, rank, world):
+        self.torch, self.ebo, self.exchange, self.rank, self.world = torch, ebo, exchange, rank, world
+        self.active = True
+        self.backend = "ebo"
+        self.transport = "libebo_hip.so's own RCCL communicator (ebo_comm_init)"
+        self.ctx = None
+        self.prefix = os.path.join("/tmp", "ebo_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+
+    def attach(self, ctx):
+        cid = self.ebo.comm_unique_id() if self.rank == 0 else None
+        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid)
+        ctx.comm_init(cid, self.rank, self.world)
+        self.ctx = ctx
+        self.d_one = self.torch.zeros(1, dtype=self.torch.float64, device="cuda")
+        self.d_all = self.torch.zeros(self.world, dtype=self.torch.float64, device="cuda")
+        self.d_pad = None
+
+    def _gather_scalar(self, value):
+        self.d_one.fill_(float(value))
+        self.ctx.allgather_device(self.d_one.data_ptr(), self.d_all.data_ptr(), 1)
+        self.torch.cuda.synchronize()
+        return self.d_all.cpu().numpy()
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        self._gather_scalar(0.0)  # returns on a rank only after every rank has entered
+
+    def reduce(self, value, op):
+        v = self._gather_scalar(value)
+        return float(v.max() if op == "MAX" else v.sum())
+
+    def allgather_rows(self, exchange, t_local, counts, out):
+        mx = max(counts)
+        tail = int(np.prod(t_local.shape[1:])) if t_local.dim() > 1 else 1
+        if min(counts) == mx:
+            self.ctx.allgather_device(t_local.data_ptr(), out.data_ptr(), mx * tail)
+            return out
+        if self.d_pad is None or self.d_pad[0].shape[0] != mx:
+            self.d_pad = (self.torch.zeros((mx,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device="cuda"),
+                          self.torch.zeros((self.world * mx,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device="cuda"))
+        pad, full = self.d_pad
+        pad[: counts[self.rank]].copy_(t_local)
+        self.ctx.allgather_device(pad.data_ptr(), full.data_ptr(), mx * tail)
+        at = 0
+        for q in range(self.world):
+            out[at:at + counts[q]].copy_(full[q * mx:q * mx + counts[q]])
+            at += counts[q]
+        return out
+
+    def reduce_sum_to_rank0(self, t_dev, staging=None):
+        self.ctx.reduce_sum_device(t_dev.data_ptr(), t_dev.data_ptr(), t_dev.numel(), root=0)
+        return t_dev
+
+    def halo_exchange(self, exchange, ctx, n_windows, band, B):
+        ptr = lambda t: t.data_ptr() if t is not None else 0
+        ctx.band_exchange_device(n_windows, band, ptr(B["top"]), ptr(B["bottom"]), ptr(B["from_above"]), ptr(B["from_below"]),
+                                 B["flag"].data_ptr())
+
+    def allgather_tracks(self, exchange, ctx, local):
+        allp, counts = self.ctx.allgather_tracks(local)
+        return allp, [int(v) for v in counts]
+
+    def close(self):
+        pass  # the communicator goes with its context (ebo_destroy)
 
 
 def bucket_rows(ev, cfg, row_b, row_e):
@@ -320,6 +413,14 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--comm", choices=("auto", "ebo", "torch"), default="auto",
+                    help="N > 1 transport: ebo = the library's own RCCL communicator (ebo_comm_init: ebo_allgather_device, "
+                         "ebo_band_exchange_device, ebo_allgather_tracks), torch = torch.distributed; auto = ebo, and torch when "
+                         "the library's communicator cannot be set up on every rank (a rehearsal over gloo is always torch)")
+    ap.add_argument("--c4-image", choices=("band", "dense"), default="band",
+                    help="c4 final image: band = every rank keeps its own rows, only halo rows travel to the two neighbours "
+                         "(SURVEY 8(e)); dense = a full image per window from every rank reduced onto rank 0 (round 3)")
+    ap.add_argument("--c4-halo", type=int, default=32, help="c4 band image: halo rows above and below a rank's own rows")
     ap.add_argument("--preheat", type=int, default=None,
                     help="untimed steps BEFORE the W warm-up steps that bring the GPU's clocks up (the same count on every "
                          "rank: steps may hold collectives).  profiles/r04_step_loop.txt: the first ~10 ms of kernels after the "
@@ -376,11 +477,42 @@ def main():
     torch.cuda.set_device(dev)
     # EBO_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, barrier, reductions,
     # all-gathers) with a single rank: a rehearsal of that path on a one-GPU box
-    comm = Comm(torch, rank, world, dev, rehearse, os.environ.get("EBO_BENCH_FORCE_DIST") == "1")
-
+    force_dist = os.environ.get("EBO_BENCH_FORCE_DIST") == "1"
     ebo = importlib.import_module("event-based-odomety_amd")
     synth = importlib.import_module("event-based-odomety_amd.synth")
     exchange = importlib.import_module("event-based-odomety_amd.exchange")
+    comm_notes = {}
+
+    def make_comm(ctx_):
+        """The run's transport, chosen once the workload's context exists (the library's communicator lives on
+        a context).  `auto`: the library's own communicator, checked with one barrier + one reduction; every
+        rank votes (files, before any collective is relied on) and ALL ranks fall back to torch.distributed
+        together when one of them could not set it up."""
+        want_ebo = (world > 1 or force_dist) and not rehearse and args.comm in ("auto", "ebo")
+        if want_ebo:
+            cand, ok, why = EboComm(torch, ebo, exchange, rank, world), True, None
+            try:
+                cand.attach(ctx_)
+                cand.barrier()
+                ok = cand.reduce(1.0, "SUM") == float(world)
+            except Exception as exc:
+                ok, why = False, repr(exc)
+            if args.comm == "ebo":
+                if not ok:
+                    raise SystemExit("--comm ebo: the library's communicator failed on rank %d: %s" % (rank, why))
+                return cand
+            if exchange.agree(cand.prefix, rank, world, ok):
+                return cand
+            comm_notes["fallback"] = "the library's communicator could not be set up on every rank (%s): torch.distributed" % (why,)
+            try:
+                ctx_.comm_destroy()
+            except Exception:
+                pass
+        c_ = TorchComm(torch, rank, world, dev, rehearse, force_dist)
+        c_.attach(ctx_)
+        return c_
+
+    comm = None
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -463,11 +595,29 @@ def main():
         n_ev_unit = np.diff(offs.astype(np.int64))
         # the final image: flows of ALL patches in patch order [window][P][2], partial image [window][H][W]
         d_grid = torch.zeros((windows_total, npx * npy, 2), dtype=torch.float64, device="cuda")
-        d_img = torch.zeros((windows_total, ih, iw), dtype=torch.float64, device="cuda") if not args.no_c4_image else None
+        # band-limited (default): the rank keeps its own image rows, halo rows go to the two neighbours.  Every rank
+        # derives every rank's plan from the same row bounds, so "no plan" (halo larger than a neighbour) is the same
+        # verdict everywhere and all ranks take the dense path together.
+        bounds = [ebo.shard_range(npy, q, n_ranks)[0] * ph for q in range(n_ranks)] + [ih]
+        band, B = None, None
+        if not args.no_c4_image and args.c4_image == "band":
+            try:
+                band = ebo.band_plan(ih, bounds, r, args.c4_halo)
+            except ebo.EboError:
+                band = None
+        if band is not None:
+            mk = lambda rows_: torch.zeros((windows_total, rows_, iw), dtype=torch.int32, device="cuda") if rows_ else None
+            B = dict(top=mk(band.top_rows), own=mk(band.own_rows), bottom=mk(band.bottom_rows),
+                     from_above=mk(band.recv_above), from_below=mk(band.recv_below),
+                     flag=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                     img_own=torch.zeros((windows_total, band.own_rows, iw), dtype=torch.float64, device="cuda"))
+        dense = not args.no_c4_image and band is None
+        d_img = torch.zeros((windows_total, ih, iw), dtype=torch.float64, device="cuda") if dense else None
         # the reduce of the partial images moves them as int32 (integer-valued counts): half the bytes, exact
         d_img32 = torch.zeros((windows_total, ih, iw), dtype=torch.int32, device="cuda") if (d_img is not None and n_ranks > 1) else None
         return dict(cfg=cfg, ctx=ctx, d_sol=d_sol, d_stats=d_stats, d_all=d_all, counts=counts, rows=rows,
-                    t_ref=np.array(t_ref, dtype=np.int64), d_grid=d_grid, d_img=d_img, d_img32=d_img32,
+                    t_ref=np.array(t_ref, dtype=np.int64), d_grid=d_grid, d_img=d_img, d_img32=d_img32, band=band, B=B,
+                    bounds=bounds, iw=iw, ih=ih,
                     n_units=n_units, n_ev_unit=n_ev_unit, n_events=len(ev), npx=npx, npy=npy,
                     windows_total=windows_total, opts=ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
 
@@ -486,6 +636,18 @@ def main():
                 S_["d_grid"][:, col:col + nq].copy_(S_["d_all"][at:at + cnt_q].view(S_["windows_total"], nq, 2))
             at += cnt_q
             col += nq
+        if S_["band"] is not None:
+            band, B = S_["band"], S_["B"]
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            S_["ctx"].count_image_band_device(S_["windows_total"], S_["t_ref"], S_["d_grid"].data_ptr(), band, ptr(B["top"]),
+                                              ptr(B["own"]), ptr(B["bottom"]), B["flag"].data_ptr())
+            comm.halo_exchange(exchange, S_["ctx"], S_["windows_total"], band, B)
+            S_["ctx"].band_finish_device(S_["windows_total"], band, ptr(B["own"]), ptr(B["from_above"]), ptr(B["from_below"]),
+                                         B["img_own"].data_ptr())
+            return
+        if S_["d_img"] is None:  # the band image escaped its halo: the dense image from here on
+            S_["d_img"] = torch.zeros((S_["windows_total"], S_["ih"], S_["iw"]), dtype=torch.float64, device="cuda")
+            S_["d_img32"] = torch.zeros((S_["windows_total"], S_["ih"], S_["iw"]), dtype=torch.int32, device="cuda") if world > 1 else None
         S_["ctx"].count_image_shard_device(S_["windows_total"], S_["t_ref"], S_["d_grid"].data_ptr(), S_["d_img"].data_ptr())
         comm.reduce_sum_to_rank0(S_["d_img"], S_.get("d_img32"))
 
@@ -494,6 +656,7 @@ def main():
     if workload in ("eval", "replicas"):
         S = setup_eval(args.config, args.windows, rank)
         ctx, cfg = S["ctx"], S["cfg"]
+        comm = make_comm(ctx)
 
         def eval_step():
             ctx.eval_device(S["d_flows"].data_ptr(), 1, S["d_out"].data_ptr())
@@ -532,7 +695,7 @@ def main():
                 pts["y"] = T["rects"][:, 1] + 12.5 + poses[:, 3]
                 T["step"] += 1
                 T["mine"] = pts  # the points this step added to the rank's tracks
-                allp, counts = comm.allgather_tracks(exchange, pts)
+                allp, counts = comm.allgather_tracks(exchange, ctx, pts)
                 T["gathered"], T["counts"] = len(allp), counts
 
         units_per_step = float(S["active"])
@@ -545,11 +708,14 @@ def main():
                   "windows_per_gpu_per_step": args.windows, "events_per_gpu_per_step": S["n_events"],
                   "scored_events_per_gpu_per_step": S["active"], "patches_per_window": S["P"],
                   "loss": "variance", "grad": "jet", "step": "one batched value+Jacobian evaluation"
-                  + (" + tracker solve + track gather" if workload == "replicas" else ""), "parallelism": par}
+                  + (" + tracker solve + track gather" if workload == "replicas" else ""), "parallelism": par,
+                  "transport": comm.transport}
+        config.update(comm_notes)
     else:
         wt = args.c4_windows if args.strong else args.c4_windows * world
         S = setup_c4(world, rank, wt)
         ctx, cfg = S["ctx"], S["cfg"]
+        comm = make_comm(ctx)
 
         def solve_only():
             ctx.solve_device(S["opts"], S["d_sol"].data_ptr(), S["d_stats"].data_ptr())
@@ -557,11 +723,18 @@ def main():
         def step():
             solve_only()
             comm.allgather_rows(exchange, S["d_sol"], S["counts"], S["d_all"])
-            if S["d_img"] is not None:
+            if not args.no_c4_image:
                 c4_image(S)
 
         step()
         torch.cuda.synchronize()
+        if S["band"] is not None and int(S["B"]["flag"].item()) != 0:
+            # a solved flow could carry an event beyond the halo (the flag is the maximum over the ranks: the same
+            # on every rank): this batch takes the dense image, as the product would
+            comm_notes["band_escaped"] = "a unit's reach exceeded the halo of %d rows: dense image + reduce" % args.c4_halo
+            S["band"] = None
+            step()
+            torch.cuda.synchronize()
         units_per_step = c4_event_evals(S)
         kernel_fn = solve_only
         roof_kernel = "k_solve_independent"
@@ -573,11 +746,28 @@ def main():
                                        "request at the point whose cost was just evaluated runs the gather pass on the image that "
                                        "evaluation left in LDS (bit-identical result; EBO_SOLVE_NO_REUSE=1 rebuilds the image)",
                   "step": "device-resident per-patch solve of the shard (ebo_solve_device) + one all-gather of the solved flows"
-                          + ("" if args.no_c4_image else " + partial final count image of the shard's events (ebo_count_image_shard)"
-                             " + one reduce of the images onto rank 0"),
-                  "parallelism": "patch rows of every window sharded over %d GPU(s), %s all-gather of flows (16 B/patch)%s per step"
-                                 % (world, "RCCL" if comm.backend == "nccl" else (comm.backend or "no"),
-                                    "" if args.no_c4_image else " and reduce of the %d x %d count images (moved as int32: exact, half the bytes of f64)" % (cfg["image"][0], cfg["image"][1]))}
+                          + ("" if args.no_c4_image else (
+                              " + band-limited final image: the shard's events counted into its own rows + a halo (ebo_count_image_band), "
+                              "halo rows to the two neighbouring ranks (send / recv), own rows finished on the rank" if S["band"] is not None
+                              else " + partial final count image of the shard's events (ebo_count_image_shard) + one reduce of the images onto rank 0")),
+                  "transport": comm.transport,
+                  "parallelism": "patch rows of every window sharded over %d GPU(s), one all-gather of flows (16 B/patch)%s per step"
+                                 % (world, "" if args.no_c4_image else (
+                                     " and one halo exchange with the neighbouring ranks" if S["band"] is not None else
+                                     " and reduce of the %d x %d count images (moved as int32: exact, half the bytes of f64)" % (cfg["image"][0], cfg["image"][1])))}
+        if not args.no_c4_image:
+            dense_bytes = cfg["image"][0] * cfg["image"][1] * 8
+            if S["band"] is not None:
+                b_ = S["band"]
+                sent = (b_.top_rows + b_.bottom_rows) * cfg["image"][0] * 4
+                config["final_image"] = {"mode": "band", "halo_rows": args.c4_halo, "own_rows": b_.own_rows,
+                                         "bytes_sent_per_rank_per_window": sent if world > 1 else 0,
+                                         "dense_f64_image_bytes": dense_bytes, "fraction_of_dense": sent / dense_bytes,
+                                         "note": "uint32 counts; interior ranks send both halos, the first and last rank one"}
+            else:
+                config["final_image"] = {"mode": "dense", "bytes_sent_per_rank_per_window": dense_bytes // 2 if world > 1 else 0,
+                                         "dense_f64_image_bytes": dense_bytes}
+        config.update(comm_notes)
 
     # ---- the timed region: W warm-up steps, barrier, EXACTLY K steps, barrier -----------------
     # Before it, untimed: the GPU idled through the set-up (event generation, uploads) and its first ~10 ms of
@@ -598,6 +788,21 @@ def main():
     dt = comm.reduce(dt, "MAX")
     total_units = comm.reduce(units_per_step, "SUM")
     comm_total_events = comm.reduce(float(S["n_events"]), "SUM") if workload == "c4" else None
+    band_counted, band_full = None, None
+    if workload == "c4" and S.get("band") is not None:
+        # untimed checks of the band image: every rank's own rows sum to the events counted; on the library's
+        # communicator the whole image is also assembled once on rank 0 (ebo_band_gather_device: owned rows only)
+        band_counted = comm.reduce(float(S["B"]["img_own"].sum().item()), "SUM")
+        band_escaped = comm.reduce(float(S["B"]["flag"].item()), "MAX")
+        if isinstance(comm, EboComm) or world == 1:
+            d_full = torch.zeros((S["windows_total"], S["ih"], S["iw"]), dtype=torch.float64, device="cuda") if rank == 0 else None
+            ctx.band_gather_device(S["windows_total"], S["bounds"], S["B"]["img_own"].data_ptr(), 0,
+                                   d_full.data_ptr() if d_full is not None else 0)
+            torch.cuda.synchronize()
+            if rank == 0:
+                full = d_full.cpu().numpy()
+                band_full = {"assembled_on_rank0": True, "integer_valued": bool(np.array_equal(full, np.round(full))),
+                             "sum_equals_own_rows_sum": bool(full.sum() == band_counted)}
 
     # ---- dominant kernel: average launch duration by HIP events on ITS stream -----------------
     kern_ms = timed(kernel_fn, max(3, args.steps))
@@ -620,7 +825,13 @@ def main():
         extras["allgather_check"] = bool(np.array_equal(got[lo:lo + len(mine)], mine)) and bool(np.isfinite(got).all())
         st = S["d_stats"].cpu().numpy()
         extras["mean_evals_per_patch"] = float((st[:, 1] + st[:, 2])[st[:, 2] > 0].mean())
-        if S["d_img"] is not None:
+        if S.get("band") is not None:
+            extras["final_image"] = {"mode": "band", "windows": int(S["windows_total"]), "events_counted": band_counted,
+                                     "events_in_batch": float(comm_total_events) if comm_total_events is not None else None,
+                                     "escaped_flag_max_over_ranks": band_escaped}
+            if band_full:
+                extras["final_image"].update(band_full)
+        elif S["d_img"] is not None:
             img = S["d_img"].cpu().numpy()
             # every event of every window of the batch lands at most once: integer-valued, sum <= events
             extras["final_image"] = {"windows": int(img.shape[0]), "integer_valued": bool(np.array_equal(img, np.round(img))),
@@ -822,17 +1033,19 @@ def main():
         # self-copy in place of the all-gather): the per-GPU reference the scaling runs compare with
         S4 = setup_c4(1, 0, args.c4_windows)
 
-        def c4_step():
+        def c4_step(image=True):
             S4["ctx"].solve_device(S4["opts"], S4["d_sol"].data_ptr(), S4["d_stats"].data_ptr())
             S4["d_all"].copy_(S4["d_sol"])
-            if S4["d_img"] is not None:
+            if image and not args.no_c4_image:
                 c4_image(S4)
 
         c4_step()
         ms4 = timed(c4_step, 5)
+        ms4_solve = timed(lambda: c4_step(False), 5)
         ee = c4_event_evals(S4)
-        extras["c4_sharded_solve_step_1gpu"] = {"ms": ms4, "windows": args.c4_windows, "event_evaluations": ee,
-                                                "mevents_per_s": rate(ee, ms4)}
+        extras["c4_sharded_solve_step_1gpu"] = {"ms": ms4, "ms_without_final_image": ms4_solve, "windows": args.c4_windows,
+                                                "event_evaluations": ee, "mevents_per_s": rate(ee, ms4),
+                                                "final_image": "band" if S4["band"] is not None else "dense"}
         S4["ctx"].close()
         del S4
 

@@ -72,3 +72,86 @@ def allgather_tracks(local, device="cpu", group=None):
     got = t_recv.cpu().numpy().reshape(world, mx * 32)
     parts = [got[q, : counts[q] * 32].copy().view(TRACK_DTYPE) for q in range(world)]
     return np.concatenate(parts), counts
+
+
+def halo_exchange(top, bottom, from_above, from_below, flag, group=None):
+    """The band-limited final image's exchange over torch.distributed (what ebo_band_exchange_device does on the
+    library's own communicator): `top` goes to rank - 1, `bottom` to rank + 1, the neighbours' halos arrive in
+    `from_above` / `from_below` (any of them None or empty: nothing travels that way), then `flag` (one int32) becomes
+    the maximum over the ranks.  Tensors on the collective's device (GPU for "nccl", CPU for "gloo")."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ops = []
+
+    def some(t):
+        return t is not None and t.numel() > 0
+    if rank > 0 and some(top):
+        ops.append(dist.P2POp(dist.isend, top, rank - 1, group))
+    if rank < world - 1 and some(bottom):
+        ops.append(dist.P2POp(dist.isend, bottom, rank + 1, group))
+    if rank > 0 and some(from_above):
+        ops.append(dist.P2POp(dist.irecv, from_above, rank - 1, group))
+    if rank < world - 1 and some(from_below):
+        ops.append(dist.P2POp(dist.irecv, from_below, rank + 1, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return flag
+
+
+def handover_bytes(prefix, rank, world, payload=None, timeout=120.0):
+    """Rank 0's `payload` (bytes: the 128-byte id of ebo_comm_unique_id) on every rank of one node, through the
+    file `prefix`.id written atomically by rank 0 -- no framework, no sockets.  Then every rank leaves a mark
+    (`prefix`.got.<rank>); rank 0 removes the files once all marks are there."""
+    import os
+    import time
+    path = prefix + ".id"
+    if rank == 0:
+        if payload is None:
+            raise ValueError("rank 0 hands the payload over")
+        tmp = path + ".tmp.%d" % os.getpid()
+        with open(tmp, "wb") as fp:
+            fp.write(payload)
+        os.replace(tmp, path)
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise TimeoutError("no %s after %.0f s" % (path, timeout))
+        time.sleep(0.01)
+    with open(path, "rb") as fp:
+        got = fp.read()
+    open("%s.got.%d" % (prefix, rank), "wb").close()
+    if rank == 0:
+        while not all(os.path.exists("%s.got.%d" % (prefix, q)) for q in range(world)):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("a rank never read %s" % path)
+            time.sleep(0.01)
+        for q in range(world):
+            os.remove("%s.got.%d" % (prefix, q))
+        os.remove(path)
+    return got
+
+
+def agree(prefix, rank, world, ok, timeout=120.0):
+    """Every rank's yes / no on every rank (files `prefix`.ok.<rank>): True when all said yes.  For decisions every
+    rank must take the same way BEFORE any collective exists (does the library's communicator work here?)."""
+    import os
+    import time
+    mine = "%s.ok.%d" % (prefix, rank)
+    tmp = mine + ".tmp"
+    with open(tmp, "w") as fp:
+        fp.write("1" if ok else "0")
+    os.replace(tmp, mine)
+    t0 = time.time()
+    votes = []
+    for q in range(world):
+        p = "%s.ok.%d" % (prefix, q)
+        while not os.path.exists(p):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("rank %d never voted" % q)
+            time.sleep(0.01)
+        with open(p) as fp:
+            votes.append(fp.read().strip() == "1")
+    return all(votes)

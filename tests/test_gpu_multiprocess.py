@@ -100,3 +100,44 @@ def test_bench_runs_at_two_ranks_without_a_launcher(extra):
         assert "patch rows sharded over 2" in line["config"]["workload"]
         assert line["config"]["grid_rows_per_gpu"] == [16, 16]
         assert line["extras"]["allgather_check"] is True
+
+
+@pytest.mark.parametrize("extra", [["--workload", "c4", "--c4-windows", "2"], ["--replicas", "--windows", "4"]])
+def test_bench_on_the_librarys_own_communicator(extra):
+    """`--comm ebo` at the one rank this box allows (EBO_BENCH_FORCE_DIST=1 takes the N > 1 code path): the id hand-over,
+    ebo_comm_init, barrier / reductions / all-gather of flows through ebo_allgather_device, the band image's
+    ebo_band_exchange_device + ebo_band_gather_device, the tracks through ebo_allgather_tracks -- no process group."""
+    env = dict(os.environ, EBO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--comm", "ebo",
+           "--no-extras", "--cpu-seconds", "0.5"] + extra
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert "ebo_comm_init" in line["config"]["transport"] and "fallback" not in line["config"]
+    if "--replicas" in extra:
+        assert line["extras"]["track_gather"]["per_rank"] == [100]
+    else:
+        fi = line["extras"]["final_image"]
+        assert line["config"]["final_image"]["mode"] == "band" and fi["mode"] == "band"
+        assert fi["assembled_on_rank0"] and fi["integer_valued"] and fi["sum_equals_own_rows_sum"]
+        assert fi["escaped_flag_max_over_ranks"] == 0.0 and 0.9 * fi["events_in_batch"] < fi["events_counted"] <= fi["events_in_batch"]
+        assert line["extras"]["allgather_check"] is True
+
+
+def test_band_and_dense_final_images_count_the_same_events_at_two_ranks():
+    """Two ranks on this box's one GPU (rehearsal over gloo: not a measurement): the c4 step with the band-limited
+    image (halo rows exchanged between the ranks) counts exactly the events the dense image + reduce counts."""
+    env = dict(os.environ, EBO_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    counted = {}
+    for mode in ("band", "dense"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--preheat", "0",
+               "--c4-windows", "1", "--c4-image", mode, "--cpu-seconds", "0.2"]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["config"]["final_image"]["mode"] == mode
+        counted[mode] = line["extras"]["final_image"]["events_counted"]
+        if mode == "band":
+            assert line["config"]["final_image"]["bytes_sent_per_rank_per_window"] == 32 * 1280 * 4
+            assert line["extras"]["final_image"]["escaped_flag_max_over_ranks"] == 0.0
+    assert counted["band"] == counted["dense"] and counted["band"] > 1.5e6
