@@ -859,15 +859,10 @@ def main():
         st = d_stats.cpu().numpy().reshape(Wn, P, 4)
         ne = np.array([[ctx.patch_info(p, w)[0] for p in range(P)] for w in range(Wn)])
         evals = (st[:, :, 1] + st[:, :, 2]) * ne
-        os.environ["EBO_SOLVE_NO_REUSE"] = "1"  # every evaluation rebuilds its image (the solve of rounds 1-2)
-        ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
-        solve_ms_full = timed(lambda: ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr()), 2)
-        os.environ.pop("EBO_SOLVE_NO_REUSE")
         extras["solve_independent"] = {
             "ms": solve_ms, "windows": Wn, "mevents_per_s": rate(float(evals.sum()), solve_ms),
             "mean_evals_per_patch": float((st[:, :, 1] + st[:, :, 2])[st[:, :, 2] > 0].mean()),
             "mean_jacobian_evals_per_patch": float(st[:, :, 2][st[:, :, 2] > 0].mean()),
-            "ms_every_evaluation_rebuilding_its_image": solve_ms_full,
             "note": "evaluations = the solver's requests; a Jacobian request at the point whose cost was just evaluated "
                     "reuses the image in LDS (same bits)"}
         # single-window latency (one window, one launch)
@@ -884,11 +879,8 @@ def main():
         c1.close()
         # window set-up: host counting sort + 8 B/event upload  vs  24 B/event upload + device
         # bucketing  vs  device bucketing of events already resident (ebo_set_windows_device)
-        t0 = time.perf_counter()
-        os.environ["EBO_BUCKET"] = "host"
-        ctx.set_windows(ev, offsets)
-        t_host = time.perf_counter() - t0
-        os.environ.pop("EBO_BUCKET")
+        # (the host-bucketing and the every-evaluation-rebuilds-its-image legs of rounds 1-3 were A/B of superseded
+        # paths: they live in tools/time_ingest.py / tools/ab_solve.py on the -DEBO_AB build now)
 
         def best_of(fn, reps=3):
             """steady-state time of one call: a warm-up, then the best of `reps` (a single shot of a
@@ -920,7 +912,6 @@ def main():
         ev24p = pin24.numpy().view(ebo.EVENT_DTYPE).reshape(-1)
         t_p24 = best_of(lambda: ctx.set_windows(ev24p, offsets))
         extras["window_setup_mevents_per_s"] = {
-            "host_bucketing_plus_upload": n_events / t_host / 1e6,
             "raw_upload_plus_device_bucketing": n_events / t_dev / 1e6,
             "raw_upload_pinned_plus_device_bucketing": n_events / t_p24 / 1e6,
             "compact8_upload_pinned_plus_device_bucketing": n_events / t_c8 / 1e6,
@@ -975,13 +966,10 @@ def main():
                          max_events=len(evs_), max_windows=256)
         ce.set_windows(evs_, offs_)
         es = {}
-        for how in ("device", "lockstep"):
-            os.environ["EBO_SOLVE_EDGE"] = how
-            ce.solve(ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
-            t0 = time.perf_counter()
-            _, ss_ = ce.solve(ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
-            es[how + "_ms"] = (time.perf_counter() - t0) * 1e3
-        os.environ.pop("EBO_SOLVE_EDGE")
+        ce.solve(ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
+        t0 = time.perf_counter()
+        _, ss_ = ce.solve(ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT))
+        es["device_ms"] = (time.perf_counter() - t0) * 1e3
         es["windows"] = 256
         es["evaluations_window0"] = int(ss_[0].num_evals_cost + ss_[0].num_evals_jac)
         extras["edge_solve_independent_reference_default"] = es

@@ -19,6 +19,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 # EBO_LIB_PATH: another build of the same library (tools/ A/B runs of two builds on one box only)
 LIB_PATH = os.environ.get("EBO_LIB_PATH") or os.path.join(HERE, "libebo_hip.so")
+# The A/B build (make ab: -DEBO_AB, the environment switches of csrc/ab_env.h and the superseded kernels).  A module
+# instance imported under the name `..._ab` (tests' `ebo_ab` fixture, tools/ab/*) binds it; the product never does.
+AB_LIB_PATH = os.path.join(HERE, "libebo_hip_ab.so")
+if __name__.endswith("_ab"):
+    LIB_PATH = AB_LIB_PATH
 HEADER_PATH = os.path.join(ROOT, "include", "ebo.h")
 
 OK = 0

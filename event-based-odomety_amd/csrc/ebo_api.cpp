@@ -167,7 +167,7 @@ int image_capacity(ebo_ctx* c, int& capDoubles, size_t& lds, size_t defaultKb = 
 	// 40 KB at three waves per SIMD (four workgroups per CU; the device-resident solve): as fast as 32 at small
 	// flows, +5-8 % near convergence (fewer sub-bands); 48 and more cost occupancy.  The batched evaluation
 	// runs four waves per SIMD and passes 31 KB: five 192-lane workgroups per CU.
-	size_t kb = env_size("EBO_LDS_KB", defaultKb);
+	size_t kb = ab_size("EBO_LDS_KB", defaultKb);
 	size_t bytes = std::min<size_t>(std::max<size_t>(kb, 4) * 1024, kLdsBudget);
 	// keep at least 24 rows of the widest canvas where that fits
 	const size_t want = static_cast<size_t>(24) * 3 * c->max_rw * sizeof(double) + headerBytes;
@@ -183,19 +183,19 @@ int image_capacity(ebo_ctx* c, int& capDoubles, size_t& lds, size_t defaultKb = 
 
 int eval_impl()
 {
-	const int v = static_cast<int>(env_size("EBO_EVAL_IMPL", 3));
+	const int v = static_cast<int>(ab_size("EBO_EVAL_IMPL", 3));
 	return (v < 0 || v > 3) ? 3 : v;
 }
 
 int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
 {
-	const size_t budget = env_size("EBO_LDS_BUDGET", kLdsBudget);
+	const size_t budget = ab_size("EBO_LDS_BUDGET", kLdsBudget);
 	const int fit = min_tiles(channels, c->max_rw, c->max_rh, budget);
 	if (fit < 0)
 	{
 		return c->fail(EBO_ERR_UNSUPPORTED, "patch too wide for LDS row tiling");
 	}
-	int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
+	int t = static_cast<int>(ab_size("EBO_EVAL_TILES", 0));
 	if (t <= 0)
 	{
 		t = fit;
@@ -208,7 +208,7 @@ int eval_geometry(ebo_ctx* c, int channels, int& tiles, int& block, size_t& lds)
 	}
 	t = std::max(t, fit);
 	tiles = t;
-	block = static_cast<int>(env_size("EBO_EVAL_BLOCK", 256));
+	block = static_cast<int>(ab_size("EBO_EVAL_BLOCK", 256));
 	if (block < 64 || block > 1024 || (block & 63))
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,1024]");
@@ -228,7 +228,7 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	L.n_units = static_cast<int>(c->units.size());
 	// one workgroup per CU (LDS-limited): a big workgroup is the only source of waves
 	// (measured, C2 x 64 windows: 256 threads 2.1, 512: 2.8, 1024: 3.3 Gevents/s)
-	L.block = static_cast<int>(env_size("EBO_EDGE_BLOCK", 0));
+	L.block = static_cast<int>(ab_size("EBO_EDGE_BLOCK", 0));
 	if (L.block != 0 && (L.block < 64 || L.block > 768 || (L.block & 63)))
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_EDGE_BLOCK must be a multiple of 64 in [64,768]");
@@ -248,7 +248,7 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	// (0.93 ms vs 0.98 / 1.27 ms for the second with the direct / short-band separable filter).
 	const size_t bytesPerPx = 3 * sizeof(double) + sizeof(int32_t);
 	const size_t aliasPerPx = 2 * sizeof(double) + sizeof(int32_t);
-	const char* layoutEnv = std::getenv("EBO_EDGE_LAYOUT");  // 0 / 1 force a layout (A/B)
+	const char* layoutEnv = ab_env("EBO_EDGE_LAYOUT");  // 0 / 1 force a layout (A/B)
 	const bool fitsTwice = headerBytes + canvasPx * aliasPerPx + 64 <= 80 * 1024 - 256;
 	// The grid's REGULAR patches decide (the last row / column of a grid absorbs the remainder of
 	// the sensor and can be almost twice as large): when their canvas fits twice, the 20 B layout
@@ -263,8 +263,8 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 							   headerBytes + (regularPx * 9 / 10) * aliasPerPx + 64 <= kLdsBudget && regularPx <= 8 * 1024;
 	L.alias_lds = layoutEnv ? (std::atoi(layoutEnv) != 0) : ((fitsTwice || regularFitsTwice || onlyAliasFits) ? 1 : 0);
 	const size_t ldsPerPx = L.alias_lds ? aliasPerPx : bytesPerPx;
-	const bool ldsEnv = std::getenv("EBO_EDGE_LDS_KB") != nullptr;
-	size_t ldsBytes = std::min<size_t>(env_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
+	const bool ldsEnv = ab_env("EBO_EDGE_LDS_KB") != nullptr;
+	size_t ldsBytes = std::min<size_t>(ab_size("EBO_EDGE_LDS_KB", 160) * 1024, kLdsBudget);
 	if (L.alias_lds && !layoutEnv && !ldsEnv && !fitsTwice && regularFitsTwice)
 	{
 		ldsBytes = 80 * 1024 - 256;  // two workgroups per CU; larger border units: global slice
@@ -398,8 +398,8 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	}
 	L.ec.stats = nullptr;
 	L.ec.mean_threshold = 0.0001;
-	L.ec.ablate = static_cast<int>(env_size("EBO_EDGE_ABLATE", 0));
-	L.ec.reserved = static_cast<int>(env_size("EBO_EDGE_SEPARABLE", 7));  // forms of the separable tensor filter (see EdgeConsts / ebo_edge.inc)
+	L.ec.ablate = static_cast<int>(ab_size("EBO_EDGE_ABLATE", 0));
+	L.ec.reserved = static_cast<int>(ab_size("EBO_EDGE_SEPARABLE", 7));  // forms of the separable tensor filter (see EdgeConsts / ebo_edge.inc)
 	return EBO_OK;
 }
 
@@ -451,8 +451,8 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 	L.fd_step = central ? c->prm.fd_step : 0.0;
 	L.impl = eval_impl();
 	L.cap_doubles = 0;
-	L.rotate = env_size("EBO_EVAL_ROT", 1) ? 1 : 0;
-	L.deal = env_size("EBO_EVAL_DEAL", 0) ? 1 : 0;
+	L.rotate = ab_size("EBO_EVAL_ROT", 1) ? 1 : 0;
+	L.deal = ab_size("EBO_EVAL_DEAL", 0) ? 1 : 0;
 	int rc;
 	if (L.impl == 0)
 	{
@@ -485,12 +485,12 @@ int run_eval_device(ebo_ctx* c, const double* d_flows, int want_jac, double* d_o
 		// workgroup, so the two regimes differ in the last bits: a window is bit-identical alone
 		// and inside a batch as long as both are on the same side of 1024 units.)
 		const int nUnits = std::max(1, static_cast<int>(c->n_flows()));
-		L.block = static_cast<int>(env_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : manyBlock));
+		L.block = static_cast<int>(ab_size("EBO_EVAL_BLOCK", nUnits < 1024 ? 512 : manyBlock));
 		if (L.block < 64 || L.block > 512 || (L.block & 63))
 		{
 			return c->fail(EBO_ERR_ARG, "EBO_EVAL_BLOCK must be a multiple of 64 in [64,512]");
 		}
-		int t = static_cast<int>(env_size("EBO_EVAL_TILES", 0));
+		int t = static_cast<int>(ab_size("EBO_EVAL_TILES", 0));
 		if (t <= 0)
 		{
 			// One workgroup per unit, unless a unit's image needs many sequential sub-bands (a
@@ -589,7 +589,7 @@ int ensure_device_modes(ebo_ctx* c, size_t nf)
 bool live_windows_of(const ebo_ctx* c, const unsigned char* modes, size_t s0, size_t s1, int windowSlots, bool wantJac,
 					 LiveWindows& live)
 {
-	const bool noCompact = std::getenv("EBO_SOLVE_NO_COMPACT") != nullptr;  // (A/B and tests: read per round)
+	const bool noCompact = ab_env("EBO_SOLVE_NO_COMPACT") != nullptr;  // (A/B and tests: read per round)
 	live.n = 0;
 	// A central-difference Jacobian round evaluates five flow sets and combines them (k_combine_variance /
 	// k_edge_central): those launches cover every unit and know neither the list nor the modes, so such a
@@ -749,7 +749,7 @@ int eval_host(ebo_ctx* c, const double* flows, double* r, double* jac, const uns
 	// Small rounds (a single window's LM round is 108 flows): the kernels read the flows from
 	// and write the results to the pinned buffers themselves; the round is one launch + one
 	// sync.  Larger rounds move the data with async copies (which really are async from pinned).
-	const size_t zeroCopyMax = env_size("EBO_ZERO_COPY_MAX", 4096);
+	const size_t zeroCopyMax = ab_size("EBO_ZERO_COPY_MAX", 4096);
 	const bool zeroCopy = nf <= zeroCopyMax;
 	std::memcpy(c->pin_flows, flows, nf * 2 * sizeof(double));
 	const double* dFlows = c->pin_flows;
@@ -836,9 +836,9 @@ struct CtxLockstepBackend
 		// amortise, so two groups in flight pay from four windows up -- 4 windows 2.3 -> 1.85 ms, 16 windows 4.1 -> 3.3 ms, 32 windows
 		// 9.2 -> 6.6 ms; until round 3 the threshold was 16 windows AND more flow slots than the zero-copy limit)
 		(void)slots;
-		return windows >= static_cast<int>(env_size("EBO_SOLVE_PIPELINE_MIN", 4)) && !std::getenv("EBO_SOLVE_NO_PIPELINE");
+		return windows >= static_cast<int>(ab_size("EBO_SOLVE_PIPELINE_MIN", 4)) && !ab_env("EBO_SOLVE_NO_PIPELINE");
 	}
-	int groups() const { return static_cast<int>(env_size("EBO_SOLVE_GROUPS", 2)); }
+	int groups() const { return static_cast<int>(ab_size("EBO_SOLVE_GROUPS", 2)); }
 	int pipeline_begin(size_t slots, int G)
 	{
 		int rc = ensure_eval_staging(c, slots);
@@ -955,7 +955,7 @@ int run_solve_device(ebo_ctx* c, const ebo_solver_opts* o, double* d_flows_out, 
 	{
 		return rc;
 	}
-	L.block = static_cast<int>(env_size("EBO_SOLVE_BLOCK", smallCanvas ? 128 : 192));
+	L.block = static_cast<int>(ab_size("EBO_SOLVE_BLOCK", smallCanvas ? 128 : 192));
 	if (L.block < 64 || L.block > 512 || (L.block & 63))
 	{
 		return c->fail(EBO_ERR_ARG, "EBO_SOLVE_BLOCK must be a multiple of 64 in [64,512]");
@@ -985,10 +985,10 @@ int count_device(ebo_ctx* c, int mode, const void* d_aux, double* d_image)
 	L.units_per_window = c->P + 1;
 	L.mode = mode;
 	{
-		const char* v = std::getenv("EBO_COUNT_IMPL");
+		const char* v = ab_env("EBO_COUNT_IMPL");
 		L.impl = (v && *v) ? std::atoi(v) : -1;
 	}
-	L.lds_kb = static_cast<int>(std::min<size_t>(env_size("EBO_COUNT_LDS_KB", 0), 160));
+	L.lds_kb = static_cast<int>(std::min<size_t>(ab_size("EBO_COUNT_LDS_KB", 0), 160));
 	L.max_window_events = 0;
 	for (const WindowInfo& wi : c->windows)
 	{
@@ -1199,7 +1199,7 @@ int solve_independent_host(ebo_ctx* c, const ebo_solver_opts* o, double* flows_o
 	// to lock step from 2048 units up: its solver ran replicated in every wave and cost the workgroup
 	// as many vector instructions as the evaluations themselves).  EBO_SOLVE_EDGE=lockstep forces the
 	// host LMs (A/B); ebo_solve_device is always the device solve.
-	const char* edgeMode = std::getenv("EBO_SOLVE_EDGE");
+	const char* edgeMode = ab_env("EBO_SOLVE_EDGE");
 	bool lockstepEdge = false;
 	if (c->prm.loss == EBO_LOSS_EDGE && edgeMode && *edgeMode)
 	{

@@ -2,6 +2,8 @@
 // side (ebo_kernels.hip) of libebo_hip.so.  Not part of the ABI.
 #pragma once
 
+#include "ab_env.h"
+
 #include <stddef.h>
 #include <stdint.h>
 

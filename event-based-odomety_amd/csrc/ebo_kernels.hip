@@ -706,6 +706,7 @@ __device__ __forceinline__ void eval_unit2(const uint64_t* __restrict__ ev, cons
 	block_sum<7>(S, red);
 }
 
+#ifdef EBO_AB  // second-generation evaluation (impl 1 / 2): kept for A/B against k_eval3, not shipped
 template <bool FIXED, bool ROT>
 __global__ void __launch_bounds__(512) k_eval2(const uint64_t* __restrict__ events, const Unit* __restrict__ units,
 						const double* __restrict__ flows, int tiles, int wantJac, int capDoubles,
@@ -757,7 +758,9 @@ __global__ void __launch_bounds__(512) k_eval2(const uint64_t* __restrict__ even
 		}
 	}
 }
+#endif  // EBO_AB
 
+#ifdef EBO_AB
 // ---------------------------------------------------------------------------
 // First-generation batched evaluation (impl 0, kept for A/B): full 3W x 3H canvas,
 // one f64 atomic per tap and channel.  Workgroup = (flow set, unit, row tile).
@@ -827,6 +830,7 @@ __global__ void k_eval_variance(const uint64_t* __restrict__ events,
 		}
 	}
 }
+#endif  // EBO_AB
 
 // Adds the row tiles of each unit in tile order and finishes the objective.
 // flow sets: 1 (C = 1 or 3), or 5 value-only sets for central differences.
@@ -2936,6 +2940,7 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		return 0;
 	}
 	const dim3 grid(L.n_units * L.tiles, L.flow_sets);
+#ifdef EBO_AB
 	if (L.impl == 0)
 	{
 		auto kern = (L.channels == 3) ? k_eval_variance<3> : k_eval_variance<1>;
@@ -2946,10 +2951,27 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
 						   L.d_flows, L.tiles, L.fd_step, L.d_partials, L.d_out, L.c);
 	}
-	else if (L.impl >= 3)
+	else if (L.impl < 3)
 	{
+		auto kern = (L.impl == 2) ? (L.rotate ? k_eval2<true, true> : k_eval2<true, false>)
+								  : (L.rotate ? k_eval2<false, true> : k_eval2<false, false>);
+		if (allow_big_lds(kern, L.lds_bytes))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
+						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
+						   L.d_partials, L.d_out, L.c);
+	}
+	else
+#endif  // EBO_AB
+	{
+#ifdef EBO_AB
 		auto kern = (L.c.inv_sigsq <= 1.0) ? (L.deal ? k_eval3<true, true> : k_eval3<true, false>)
 										   : (L.deal ? k_eval3<false, true> : k_eval3<false, false>);
+#else
+		auto kern = (L.c.inv_sigsq <= 1.0) ? k_eval3<true, false> : k_eval3<false, false>;
+#endif
 		if (allow_big_lds(kern, L.lds_bytes))
 		{
 			return -2;
@@ -2963,18 +2985,6 @@ int launch_eval_variance(const EvalLaunch& L, void* stream)
 		hipLaunchKernelGGL(kern, live.n > 0 ? dim3(live.n * live.upw) : grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
 						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
 						   L.d_partials, L.d_out, L.c, fusedPath ? L.d_modes : nullptr, live);
-	}
-	else
-	{
-		auto kern = (L.impl == 2) ? (L.rotate ? k_eval2<true, true> : k_eval2<true, false>)
-								  : (L.rotate ? k_eval2<false, true> : k_eval2<false, false>);
-		if (allow_big_lds(kern, L.lds_bytes))
-		{
-			return -2;
-		}
-		hipLaunchKernelGGL(kern, grid, dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units,
-						   L.d_flows, L.tiles, L.channels == 3 ? 1 : 0, L.cap_doubles, L.fd_step,
-						   L.d_partials, L.d_out, L.c);
 	}
 	if (check_launch())
 	{
@@ -3289,13 +3299,13 @@ int launch_optimizer_solve(const OptLaunch& L, void* stream)
 	// measured (25x25 patches): 256 lanes best up to ~100 patches (0.27 / 0.38 ms for 1 / 100), 128
 	// lanes at 1000 (1.13 vs 1.32 ms); 384+ lanes slower everywhere.  EBO_OPT_BLOCK for A/B.
 	int block = L.n_patches >= 512 ? 128 : 256;
-	if (const char* v = std::getenv("EBO_OPT_BLOCK"))
+	if (const char* v = ab_env("EBO_OPT_BLOCK"))
 	{
 		block = std::min(std::max((std::atoi(v) / 64) * 64, 64), 256);
 	}
 	hipLaunchKernelGGL(k_optimizer_solve, dim3(L.n_patches), dim3(block), lds, static_cast<hipStream_t>(stream),
 					   L.d_grid, L.img_w, L.img_h, L.d_patches, L.d_nabla, L.d_x, L.d_stats, L.huber, L.s,
-					   std::getenv("EBO_OPT_NO_SPECULATE") ? 0 : 1);
+					   ab_env("EBO_OPT_NO_SPECULATE") ? 0 : 1);
 	return check_launch();
 }
 
@@ -3571,7 +3581,7 @@ int launch_solve_edge(const EdgeLaunch& L, const SolveConsts& o, double* d_flows
 		return -2;
 	}
 	hipLaunchKernelGGL(kern, dim3(L.n_units), dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units, L.cap_px,
-					   L.d_scratch, L.scratch_stride, d_flows_out, d_stats, L.c, L.ec, o, std::getenv("EBO_SOLVE_NO_REUSE") ? 1 : 0);
+					   L.d_scratch, L.scratch_stride, d_flows_out, d_stats, L.c, L.ec, o, ab_env("EBO_SOLVE_NO_REUSE") ? 1 : 0);
 	return check_launch();
 }
 
@@ -3596,16 +3606,20 @@ int launch_solve_independent(const SolveLaunch& L, void* stream)
 		return 0;
 	}
 	const bool smallExp = L.c.inv_sigsq <= 1.0;
+#ifdef EBO_AB
 	auto kern = (L.impl == 1)   ? k_solve_independent<1>
 				: (L.impl == 2) ? k_solve_independent<2>
 				: smallExp		? k_solve_independent<3>
 								: k_solve_independent<4>;
+#else
+	auto kern = smallExp ? k_solve_independent<3> : k_solve_independent<4>;
+#endif
 	if (allow_big_lds(kern, L.lds_bytes))
 	{
 		return -2;
 	}
 	hipLaunchKernelGGL(kern, dim3(L.n_units), dim3(L.block), L.lds_bytes, s, L.d_events,
-					   L.d_units, L.cap_doubles, L.d_flows_out, L.d_stats, L.c, L.s, std::getenv("EBO_SOLVE_NO_REUSE") ? 1 : 0);
+					   L.d_units, L.cap_doubles, L.d_flows_out, L.d_stats, L.c, L.s, ab_env("EBO_SOLVE_NO_REUSE") ? 1 : 0);
 	return check_launch();
 }
 
@@ -3688,7 +3702,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			if (lds <= 160 * 1024 && allow_big_lds(kern, lds) == 0)
 			{
 				const int groups = (L.n_windows + 7) / 8;
-				const char* be = std::getenv("EBO_COUNT_BLOCK");
+				const char* be = ab_env("EBO_COUNT_BLOCK");
 				const int tileBlock = be && *be ? std::max(64, std::min(1024, (std::atoi(be) / 64) * 64))
 												: (budgetAll <= 38 * 1024 ? 512 : 1024);
 				hipLaunchKernelGGL(kern, dim3(groups * bestX * bestY * 8), dim3(tileBlock), lds, s, L.d_events, L.d_units,
@@ -3862,7 +3876,7 @@ int launch_count_image(const CountLaunch& L, void* stream)
 			const int widest = std::max(perTile * L.c.patch_w, L.c.image_w - lastLo * L.c.patch_w);
 			tileRowBytes = static_cast<size_t>(widest) * pxBytes;
 		}
-		if (const char* v = std::getenv("EBO_COUNT_COLTILES"))  // A/B: 1 = off
+		if (const char* v = ab_env("EBO_COUNT_COLTILES"))  // A/B: 1 = off
 		{
 			if (std::atoi(v) == 1)
 			{

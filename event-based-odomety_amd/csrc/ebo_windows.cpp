@@ -164,7 +164,7 @@ static int set_windows_on_device(ebo_ctx* c, const void* d_raw, const size_t* of
 		}
 		// three groups: 12.8 M compact events take 2.63 / 2.40 / 2.34 / 2.37 / 2.88 ms in 1 / 2 / 3 / 4 / 8 groups
 		// (every group is five launches and two event hand-offs; a plain copy of the bytes 1.79 ms)
-		const size_t wantGroups = std::min<size_t>(std::max<size_t>(env_size("EBO_INGEST_GROUPS", 3), 1), 7);
+		const size_t wantGroups = std::min<size_t>(std::max<size_t>(ab_size("EBO_INGEST_GROUPS", 3), 1), 7);
 		const size_t perGroup = std::max<size_t>((total * recBytes + wantGroups - 1) / wantGroups, static_cast<size_t>(8) << 20);
 		int w0 = 0, g = 0;
 		// the upload may not overtake earlier work of the context's stream that still reads d_raw
@@ -325,7 +325,7 @@ int ebo_set_windows(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, int 
 	{
 		return c->fail(EBO_ERR_ARG, "more events than max_events");
 	}
-	const char* mode = std::getenv("EBO_BUCKET");
+	const char* mode = ab_env("EBO_BUCKET");
 	if ((mode && std::strcmp(mode, "host") == 0) || !device_bucketing_fits(c))
 	{
 		return set_windows_host(c, ev, offsets, n_windows);

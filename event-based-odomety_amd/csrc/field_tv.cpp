@@ -65,22 +65,22 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 	tvf_carve(A, M, w, h, workspace, &xbest);
 	{
 		// EBO_TVF_PRECOND=jacobi: the diagonal preconditioner (A/B, ~30x more CG iterations)
-		const char* pre = std::getenv("EBO_TVF_PRECOND");
+		const char* pre = ab_env("EBO_TVF_PRECOND");
 		if (pre && std::strcmp(pre, "jacobi") == 0)
 		{
 			M.levels = 0;
 		}
 	}
 	// iterations between two looks at the residual: multigrid converges in a few tens
-	const char* chunkEnv = std::getenv("EBO_TVF_CG_CHUNK");
+	const char* chunkEnv = ab_env("EBO_TVF_CG_CHUNK");
 	const int cgChunk = chunkEnv ? std::max(2, std::atoi(chunkEnv) & ~1) : (M.levels >= 2 ? 8 : 32);
 	A.huber_a = use_l1 ? 1e-5 : 0.0;  // feature_detector.cpp:182,187
 	A.lm_lo = o.min_lm_diagonal;
 	A.lm_hi = o.max_lm_diagonal;
 	const size_t vecBytes = static_cast<size_t>(A.n) * sizeof(double2);
-	const char* tolEnv = std::getenv("EBO_TVF_CG_TOL");
+	const char* tolEnv = ab_env("EBO_TVF_CG_TOL");
 	const double cgTol = tolEnv ? std::atof(tolEnv) : 1e-13;
-	const char* capEnv = std::getenv("EBO_TVF_CG_MAX");
+	const char* capEnv = ab_env("EBO_TVF_CG_MAX");
 	const int cgMax = capEnv ? std::atoi(capEnv) : 200000;
 
 	auto fail = [&](const char* what) {
@@ -140,7 +140,7 @@ int field_tv_solve(int w, int h, float* d_field, const int* d_fixed, int n_fixed
 		}
 	} gh;
 	hipGraphExec_t chunkGraph = nullptr;
-	const char* graphEnv = std::getenv("EBO_TVF_GRAPH");
+	const char* graphEnv = ab_env("EBO_TVF_GRAPH");
 	if (!graphEnv || std::atoi(graphEnv) != 0)
 	{
 		if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess)

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "host_lm.h"
+#include "ab_env.h"
 #include "host_pool.h"
 
 namespace ebo
@@ -51,7 +52,7 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 	// without another round trip.  The solver sees the same numbers in the same order (same kernel, same point):
 	// same trajectory, same evaluation counts, fewer rounds.  Applied to rounds of at most specMax running windows
 	// (EBO_SOLVE_SPECULATE, default 8; 0 = never).
-	const char* specEnv = std::getenv("EBO_SOLVE_SPECULATE");
+	const char* specEnv = ab_env("EBO_SOLVE_SPECULATE");
 	const size_t specMax = specEnv ? static_cast<size_t>(std::max(0, std::atoi(specEnv))) : 8;
 	std::vector<unsigned char> spec(static_cast<size_t>(Wn), 0);
 	std::vector<double> specPoint(specMax ? static_cast<size_t>(Wn) * P * 2 : 0);
@@ -205,7 +206,7 @@ int lockstep_global(Backend& be, int Wn, int P, std::vector<HostLm>& lm, std::ve
 				tSup += ms(t2, t3);
 				const auto t4 = now();
 				tReq += ms(t3, t4);
-				if (trace && std::getenv("EBO_SOLVE_TRACE_ROUNDS"))
+				if (trace && ab_env("EBO_SOLVE_TRACE_ROUNDS"))
 				{
 					std::fprintf(stderr, "[ebo]   round %4d group %d live %4zu jac %d: wait %.3f supply %.3f request %.3f ms\n", rounds, g,
 								 live.size(), gJac[g] ? 1 : 0, ms(t1, t2), ms(t2, t3), ms(t3, t4));

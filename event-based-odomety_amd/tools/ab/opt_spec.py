@@ -11,6 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "event-based-odomety_amd", "tools"))
+# the switches this tool flips (EBO_*) exist only in the A/B build (make ab; csrc/ab_env.h)
+os.environ.setdefault("EBO_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "libebo_hip_ab.so"))
 ebo = importlib.import_module("event-based-odomety_amd")
 from time_optimizer import scene  # noqa: E402
 

@@ -7,6 +7,9 @@ import ctypes as C, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+import os
+# the switches this tool flips (EBO_*) exist only in the A/B build (make ab; csrc/ab_env.h)
+os.environ.setdefault("EBO_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libebo_hip_ab.so"))
 ebo = importlib.import_module("event-based-odomety_amd")
 ebo.LIB_PATH = os.path.join(os.path.dirname(ebo.LIB_PATH), "libebo_hip_prof.so")
 synth = importlib.import_module("event-based-odomety_amd.synth")

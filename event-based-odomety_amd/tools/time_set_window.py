@@ -3,6 +3,9 @@ bucketing + unit table back) with the stage split of EBO_INGEST_TRACE.  usage: t
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import os
+# the switches this tool flips (EBO_*) exist only in the A/B build (make ab; csrc/ab_env.h)
+os.environ.setdefault("EBO_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libebo_hip_ab.so"))
 ebo = importlib.import_module("event-based-odomety_amd")
 synth = importlib.import_module("event-based-odomety_amd.synth")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 15000

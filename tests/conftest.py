@@ -30,6 +30,21 @@ def ebo():
 
 
 @pytest.fixture(scope="session")
+def ebo_ab():
+    """A second instance of the same plumbing bound to libebo_hip_ab.so (-DEBO_AB): the only build that reads
+    the EBO_* switches of csrc/ab_env.h.  For the tests that force an implementation, a block shape or an ablation
+    and compare it with what the shipped library picks by itself."""
+    import importlib.util
+    pkg = os.path.join(ROOT, "event-based-odomety_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("event_based_odomety_amd_ab", pkg,
+                                                  submodule_search_locations=[os.path.dirname(pkg)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
 def synth():
     return importlib.import_module("event-based-odomety_amd.synth")
 

@@ -248,7 +248,8 @@ def test_device_compensate_events_with_smoothed_field(ebo, orc, synth):
 
 
 @pytest.mark.gpu
-def test_device_field_tv_diagonal_preconditioner_agrees(ebo, orc, monkeypatch):
+def test_device_field_tv_diagonal_preconditioner_agrees(ebo_ab, orc, monkeypatch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """EBO_TVF_PRECOND=jacobi (the fallback) and the multigrid preconditioner solve the same
     systems: same LM trajectory, same field, ~20x apart in CG iterations."""
     w, h = 96, 72

@@ -16,7 +16,8 @@ def build(ebo, synth, config, ev, offsets, **kw):
 
 
 @pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 5, 20000), (4, 2, 150000)])
-def test_device_bucketing_equals_host_bucketing(ebo, orc, synth, monkeypatch, config, n_windows, n_events):
+def test_device_bucketing_equals_host_bucketing(ebo_ab, orc, synth, monkeypatch, config, n_windows, n_events):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     ev, offsets, gt = synth.make_stream(config, n_windows, n_events=n_events)
     ev["x"][3] = -2  # strays
     ev["y"][11] = 30000 // 2
@@ -48,7 +49,8 @@ def test_device_bucketing_equals_host_bucketing(ebo, orc, synth, monkeypatch, co
 
 
 @pytest.mark.parametrize("quantum_us", [1000, 50000])
-def test_quantised_timestamps_keep_results_and_time(ebo, orc, synth, monkeypatch, quantum_us):
+def test_quantised_timestamps_keep_results_and_time(ebo_ab, orc, synth, monkeypatch, quantum_us):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Recordings with quantised stamps (a simulator's frame times, a millisecond driver): hundreds to
     thousands of events of a unit share ONE timestamp.  The closed-form canonical order of k_bucket_canon walks
     a run of equal stamps once per record (O(run^2)); runs above 32 records take the bitonic network instead --

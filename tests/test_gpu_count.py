@@ -18,7 +18,8 @@ def _prm(orc, c):
 
 @pytest.mark.parametrize("impl", ["0", "1", "2", "3", "4", "5", "auto"])
 @pytest.mark.parametrize("config,n_windows,n_events", [(0, 1, 15000), (2, 70, 9000), (3, 3, 70000), (4, 2, 60000)])
-def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config, n_windows, n_events):
+def test_count_image_implementations(ebo_ab, orc, synth, monkeypatch, impl, config, n_windows, n_events):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     if impl == "auto":
         monkeypatch.delenv("EBO_COUNT_IMPL", raising=False)
     else:
@@ -50,7 +51,8 @@ def test_count_image_implementations(ebo, orc, synth, monkeypatch, impl, config,
 
 
 @pytest.mark.parametrize("impl", ["1", "2", "5"])
-def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypatch, impl):
+def test_count_image_more_than_65535_events_per_window(ebo_ab, orc, synth, monkeypatch, impl):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """16-bit packed counters are only used below 65536 events per window."""
     monkeypatch.setenv("EBO_COUNT_IMPL", impl)
     cfg = synth.CONFIGS[2]
@@ -66,7 +68,8 @@ def test_count_image_more_than_65535_events_per_window(ebo, orc, synth, monkeypa
 
 
 @pytest.mark.parametrize("lds_kb", ["12", "24", "150"])
-def test_patch_row_bands_any_band_size_and_large_flows(ebo, orc, synth, monkeypatch, lds_kb):
+def test_patch_row_bands_any_band_size_and_large_flows(ebo_ab, orc, synth, monkeypatch, lds_kb):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """impl 2 with bands of one patch row up to the whole image, flows large enough that most
     events leave their band (overflow list) or the image."""
     monkeypatch.setenv("EBO_COUNT_IMPL", "2")
@@ -93,7 +96,8 @@ def test_patch_row_bands_any_band_size_and_large_flows(ebo, orc, synth, monkeypa
 @pytest.mark.parametrize("impl", ["1", "3", "4"])
 @pytest.mark.parametrize("image,patch", [((16383, 24), (2, 24)), ((16383, 24), (3, 5)), ((16000, 20), (127, 1)),
                                          ((9000, 30), (8999, 7)), ((40, 16383), (1, 16383)), ((64, 48), (1, 1))])
-def test_patch_of_an_event_from_its_coordinates(ebo, orc, monkeypatch, impl, image, patch):
+def test_patch_of_an_event_from_its_coordinates(ebo_ab, orc, monkeypatch, impl, image, patch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """The warped-count kernels find an event's patch as min(x / patch_w, npx - 1) with one
     multiply-high by a precomputed reciprocal: exact over the whole 15-bit coordinate range, for
     divisors from 1 to the sensor size, ragged last patches, and events outside the sensor (which
@@ -122,7 +126,8 @@ def test_patch_of_an_event_from_its_coordinates(ebo, orc, monkeypatch, impl, ima
 @pytest.mark.parametrize("w,h,pw,ph,n_events,lds_kb", [(347, 261, 21, 16, 30000, 16), (347, 261, 21, 16, 70000, 24),
                                                       (64, 48, 7, 5, 4000, 1), (1280, 720, 40, 22, 200000, 0),
                                                       (346, 260, 21, 16, 50000, 0), (240, 180, 30, 22, 20000, 40)])
-def test_tiled_count_image_odd_sizes_and_wide_counters(ebo, orc, synth, monkeypatch, impl, w, h, pw, ph, n_events, lds_kb):
+def test_tiled_count_image_odd_sizes_and_wide_counters(ebo_ab, orc, synth, monkeypatch, impl, w, h, pw, ph, n_events, lds_kb):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """k_count_tiles (impl 5) and k_count_sweep (impl 6) on sizes that exercise their edges: odd image
     widths (no 16-byte row stores, packed counters shared between rows), tiles / strips that do not
     divide the image, 32-bit counters (>= 65536 events per window), tiny tiles and bands (every unit

@@ -64,7 +64,8 @@ def test_edge_eval_value_and_jacobian(ebo, orc, synth, config, n_events):
 
 
 @pytest.mark.parametrize("forms,layout", [("0", "0"), ("0", "1"), ("1", "0"), ("7", "0"), ("7", "1")])
-def test_edge_tensor_filter_forms_and_layouts(ebo, orc, synth, monkeypatch, forms, layout):
+def test_edge_tensor_filter_forms_and_layouts(ebo_ab, orc, synth, monkeypatch, forms, layout):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Every selectable form of the structure-tensor filter (direct 49-tap, band buffers, register
     runs) on both LDS layouts gives the oracle's value and Jacobian (random flows: no exact ties)."""
     monkeypatch.setenv("EBO_EDGE_SEPARABLE", forms)
@@ -101,7 +102,8 @@ def test_edge_penalty_branch_and_sparse_images(ebo, orc, synth):
         assert taken[1] == 0 and taken[2] == 0
 
 
-def test_edge_global_memory_fallback(ebo, orc, synth, monkeypatch):
+def test_edge_global_memory_fallback(ebo_ab, orc, synth, monkeypatch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Boxes that do not fit LDS use the per-unit global slice: same numbers."""
     ev, gt = synth.make_window(2, n_events=30000)
     monkeypatch.setenv("EBO_EDGE_LDS_KB", "24")  # far too small for a 30x22 patch's box
@@ -153,7 +155,8 @@ def test_reference_configuration_end_to_end(ebo, orc, synth):
 
 @pytest.mark.parametrize("how", ["device", "lockstep"])
 @pytest.mark.parametrize("iters", [4, 8, 10])
-def test_edge_independent_solve_lockstep(ebo, orc, synth, monkeypatch, iters, how):
+def test_edge_independent_solve_lockstep(ebo_ab, orc, synth, monkeypatch, iters, how):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Per-patch problems (TV off) with the edge loss, the reference's own objective: the whole LM
     in one launch (k_solve_edge, the default) and, for A/B, host LMs in lock step over batched
     device evaluations; capped below the chaos horizon (DESIGN.md section 2), which is shorter
@@ -174,7 +177,8 @@ def test_edge_independent_solve_lockstep(ebo, orc, synth, monkeypatch, iters, ho
 
 
 @pytest.mark.parametrize("config,windows", [(0, 8), (2, 2), (3, 1)])
-def test_edge_device_solve_equals_the_lockstep_solve(ebo, synth, monkeypatch, config, windows):
+def test_edge_device_solve_equals_the_lockstep_solve(ebo_ab, synth, monkeypatch, config, windows):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """ebo_solve_device with the edge loss (no EBO_ERR_UNSUPPORTED any more): the same flows and
     per-patch statistics as the host-driven lock-step solve of the same windows, run to run
     identical bits, also where boxes spill into the global-memory slices (C3's corner patches)."""

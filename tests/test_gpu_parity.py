@@ -90,7 +90,8 @@ def test_contrast_image_channels(ebo, orc, synth):
 
 
 @pytest.mark.parametrize("tiles", ["1", "2", "3", "7"])
-def test_row_tiling_is_invisible(ebo, orc, synth, tiles, monkeypatch):
+def test_row_tiling_is_invisible(ebo_ab, orc, synth, tiles, monkeypatch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     ev, gt = synth.make_window(0, n_events=15000)
     monkeypatch.setenv("EBO_EVAL_TILES", tiles)
     with ctx_for(ebo, synth, 0) as c:
@@ -102,7 +103,8 @@ def test_row_tiling_is_invisible(ebo, orc, synth, tiles, monkeypatch):
 
 
 @pytest.mark.parametrize("block", ["64", "128", "512"])
-def test_block_size_is_invisible(ebo, orc, synth, block, monkeypatch):
+def test_block_size_is_invisible(ebo_ab, orc, synth, block, monkeypatch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     ev, gt = synth.make_window(0, n_events=15000)
     monkeypatch.setenv("EBO_EVAL_BLOCK", block)
     with ctx_for(ebo, synth, 0) as c:
@@ -423,7 +425,8 @@ def test_error_behaviour(ebo, synth):
         assert r.shape == (1, c.P)
 
 
-def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
+def test_evaluation_rounds_with_and_without_zero_copy(ebo_ab, synth, monkeypatch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Host-driven solves hand flows and results through pinned memory the kernels access directly
     (small rounds) or through explicit async copies (large ones, EBO_ZERO_COPY_MAX): same bits (variance
     loss: its evaluation is bit-reproducible; the edge loss's f64 LDS atomics are not)."""
@@ -445,7 +448,8 @@ def test_evaluation_rounds_with_and_without_zero_copy(ebo, synth, monkeypatch):
 
 @pytest.mark.parametrize("loss", ["variance", "edge"])
 @pytest.mark.parametrize("n", [1, 5, 19])
-def test_speculative_jacobians_in_lock_step_keep_the_bits(ebo, synth, monkeypatch, loss, n):
+def test_speculative_jacobians_in_lock_step_keep_the_bits(ebo_ab, synth, monkeypatch, loss, n):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Once few windows are running, a window that asks for the cost at a candidate is evaluated with its Jacobian
     as well, and the solver's next request -- value and Jacobian at that very point, if it accepts the step -- is
     answered from that evaluation without another round.  The solver sees the same numbers in the same order: flows,
@@ -473,7 +477,8 @@ def test_speculative_jacobians_in_lock_step_keep_the_bits(ebo, synth, monkeypatc
 
 @pytest.mark.parametrize("loss", ["variance", "edge"])
 @pytest.mark.parametrize("config", [0, 2])
-def test_device_solve_reusing_the_image_of_an_accepted_step_keeps_the_bits(ebo, synth, monkeypatch, loss, config):
+def test_device_solve_reusing_the_image_of_an_accepted_step_keeps_the_bits(ebo_ab, synth, monkeypatch, loss, config):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """The device-resident per-patch solve evaluates the cost at a candidate and, on acceptance, value and Jacobian
     at the same point; the second evaluation starts from what the first left in LDS (variance loss: the image, gather
     pass only; edge loss: image, eigenvalues and directions, from the window maxima on).  Same operations on the
@@ -503,7 +508,8 @@ def test_device_solve_reusing_the_image_of_an_accepted_step_keeps_the_bits(ebo, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("loss", ["variance", "edge"])
 @pytest.mark.parametrize("n", [6, 41])
-def test_thinned_out_rounds_as_window_lists_keep_the_bits(ebo, synth, monkeypatch, loss, n):
+def test_thinned_out_rounds_as_window_lists_keep_the_bits(ebo_ab, synth, monkeypatch, loss, n):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """Late in a lock-step solve few windows of a batch are still running; a round then launches workgroups for
     those windows' units only (a list in the kernel arguments, flows and results through pinned memory) instead
     of every unit with a mode table and copies.  Same evaluations of the same points: flows, iteration counts and
@@ -529,7 +535,8 @@ def test_thinned_out_rounds_as_window_lists_keep_the_bits(ebo, synth, monkeypatc
 
 
 @pytest.mark.parametrize("loss", ["variance", "edge"])
-def test_central_difference_rounds_never_take_the_window_list(ebo, synth, monkeypatch, loss):
+def test_central_difference_rounds_never_take_the_window_list(ebo_ab, synth, monkeypatch, loss):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """A central-difference Jacobian round launches five flow sets and a combine kernel over EVERY unit; those
     launches know no window list.  Such rounds must take the full path (which copies back only the half's own
     slots): in the pipelined driver (41 windows, two halves in flight) the solve equals, bit for bit, the
@@ -557,7 +564,8 @@ def test_central_difference_rounds_never_take_the_window_list(ebo, synth, monkey
     assert len({s[0] for s in out[0][1]}) > 1  # windows stop at different rounds: thinned-out rounds happened
 
 
-def test_pipelined_lock_step_solve_equals_the_plain_one(ebo, synth, monkeypatch):
+def test_pipelined_lock_step_solve_equals_the_plain_one(ebo_ab, synth, monkeypatch):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """With four or more windows the TV-coupled host LM runs two halves in flight (one half's LM steps
     on the host while the device evaluates the other): per window the same requests in the same
     order, so the same bits as the one-round-at-a-time loop; and the same answer as a window alone."""

@@ -287,7 +287,8 @@ def test_device_solve_matches_oracle(ebo, orc, iters):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("iters", [10, 40])
-def test_speculative_linearisation_keeps_the_bits(ebo, orc, monkeypatch, iters):
+def test_speculative_linearisation_keeps_the_bits(ebo_ab, orc, monkeypatch, iters):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
     """The tracker solve evaluates a candidate's cost together with the Jacobian sums of that point (one pass over
     the pixels) and skips the linearisation of an accepted step; the candidate's cost is the double path's.  Poses,
     flow directions, iteration and evaluation counts, final costs: bit for bit those of the two-pass loop."""
