@@ -720,7 +720,7 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 		// the canonical order of a unit (ascending packed record; units above 8192 events stay in
 		// list order), as the window paths leave it: a patch loaded here evaluates to the same bits as
 		// the same patch inside a window
-		if (n >= 2 && n <= 8192)
+		if (n >= 2 && n <= 8192 && !ab_env("EBO_KEEP_ORDER"))  // (A/B build: the list order, for the reference-order diagnostic)
 		{
 			std::sort(c->h_packed.begin() + static_cast<std::ptrdiff_t>(base),
 					  c->h_packed.begin() + static_cast<std::ptrdiff_t>(base + n));

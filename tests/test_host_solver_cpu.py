@@ -142,3 +142,34 @@ def test_abi_host_solver_state_machine(ebo, orc, synth):
     assert summ.final_cost == pytest.approx(so.final_cost, rel=1e-9)
     with pytest.raises(ebo.EboError):
         ebo.HostSolver(0, 3, np.zeros(0))
+
+
+def test_variance_loss_with_tv_starts_in_a_spurious_minimum_on_the_cpu_alone(orc, synth):
+    """Why the north-star objective under the reference's own coupling (variance loss + TV 1e3, start at zero flow,
+    feature_detector.cpp:318-326) returns its start point -- shown on the CPU oracle alone, no device involved.
+    At exactly zero flow every event sits on an integer position, and compensateEvents truncates the warped
+    coordinate (`int(c)`, contrast_functor.h:59,63): an ARBITRARILY small flow puts the events it moves in the
+    negative direction into the bin below, their 7x7 splat window shifts by a pixel, the image changes by a finite
+    amount and the variance drops.  So the cost JUMPS up by the same finite amount for a step of 1e-12 and of 1e-9 --
+    a discontinuity, not a slope -- although the gradient direction is a descent direction further out.  Every LM
+    step lands on the upper side of the jump and is rejected until the trust region is ~1e-17: the solve ends where
+    it started.  (The edge loss has the same truncation but a gain that outruns the jump within the trust region.)"""
+    ev, _ = synth.make_window(0, n_events=15000)
+    prm = orc.default_params(loss=1)  # variance loss, compensateTVweight 1e3
+    flows, _, summ = orc.compensate_events_contrast(ev, prm, orc.default_solver(), want_image=False)
+    assert summ.iterations >= 10 and np.abs(flows).max() < 1e-12
+    P = flows.shape[0]
+    r0, J0, active, _ = orc.window_eval(ev, prm, np.zeros((P, 2)))
+    g = r0[:, None] * J0
+    d = -g / np.abs(g).max()  # steepest descent of the data terms, largest component 1
+
+    def dcost(step):
+        r, _, _, _ = orc.window_eval(ev, prm, step * d)
+        return 0.5 * float((r ** 2).sum() - (r0 ** 2).sum())
+    tiny, small, far = dcost(1e-12), dcost(1e-9), dcost(1e-2)
+    print("data cost against zero flow: step 1e-12 %+.3f, 1e-9 %+.3f, 1e-2 %+.3f" % (tiny, small, far))
+    assert tiny > 1.0 and abs(small - tiny) < 0.1 * tiny  # the same jump whatever the step: a discontinuity
+    assert far < 0.0                                      # and a real descent direction beyond it
+    # the slope the Jacobian promises is orders of magnitude below the jump for any step LM would accept
+    predicted = float((g * (1e-9 * d)).sum())
+    assert abs(predicted) < 1e-3 * tiny
