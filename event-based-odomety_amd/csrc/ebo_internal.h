@@ -44,6 +44,57 @@ struct Unit
 };
 static_assert(sizeof(Unit) == 28, "Unit layout");
 
+// Canonical order inside a unit (units of 2 .. 8192 events; larger ones stay in list order): the records ranked
+// ascending as u64 -- by (uint32) dt = t_ref - t, then by the coordinate word -- and then DEALT OUT with a fixed
+// stride: the record of rank (q * stride) mod n sits at position q.  Rank order is time order, and on a moving edge
+// events that follow each other in time are neighbours in space: 64 consecutive records then splat onto overlapping
+// 7 x 7 windows and their LDS atomics hit the same words (k_eval3: 64 % of LDS cycles were bank conflicts).  With the
+// stride, consecutive positions are far apart in time, i.e. scattered over the patch: k_eval3 C3 x 64 windows
+// 0.543 -> 0.500 ms, C2 0.160 -> 0.150, C4 0.352 -> 0.330 (profiles/r04_event_order.txt; strides 101 .. 151 are
+// within 1 % of each other, row-sorted orders are 16-27 % SLOWER).  The order depends on the unit's events only
+// (never on the batch), is unique, and is the same in every loading path (host sort, device bucketing, patches).
+constexpr uint32_t kOrderStride = 127;
+inline __host__ __device__ uint32_t order_stride(uint32_t n)  // coprime to n, 1 <= stride < max(n, 2)
+{
+	if (n < 3)
+	{
+		return 1;
+	}
+	uint32_t st = kOrderStride % n;
+	st = st == 0 ? 1 : st;
+	for (;; ++st)
+	{
+		uint32_t a = st, b = n;
+		while (b)
+		{
+			const uint32_t t = a % b;
+			a = b;
+			b = t;
+		}
+		if (a == 1)
+		{
+			return st;
+		}
+	}
+}
+// position of the record of canonical rank r: q with (q * stride) mod n == r, i.e. q = r * stride^-1 mod n
+inline __host__ __device__ uint32_t order_inverse(uint32_t st, uint32_t n)
+{
+	// extended Euclid on (st, n); n <= 8192
+	int t0 = 0, t1 = 1;
+	int r0 = static_cast<int>(n), r1 = static_cast<int>(st);
+	while (r1 != 0)
+	{
+		const int q = r0 / r1;
+		const int r2 = r0 - q * r1, t2 = t0 - q * t1;
+		r0 = r1;
+		r1 = r2;
+		t0 = t1;
+		t1 = t2;
+	}
+	return static_cast<uint32_t>(t0 < 0 ? t0 + static_cast<int>(n) : t0) % (n ? n : 1);
+}
+
 static const uint32_t kUnitActive = 1u;
 static const uint32_t kUnitStray = 2u;
 

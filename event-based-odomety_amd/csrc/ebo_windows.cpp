@@ -5,6 +5,28 @@
 
 using namespace ebo;
 
+namespace
+{
+// the canonical order of a unit (ebo_internal.h: ranks ascending, dealt out with order_stride), host side
+void canonical_order(uint64_t* p, uint32_t n)
+{
+	std::sort(p, p + n);
+	const uint32_t st = order_stride(n);
+	if (st == 1)
+	{
+		return;
+	}
+	std::vector<uint64_t> tmp(p, p + n);
+	uint32_t r = 0;
+	for (uint32_t q = 0; q < n; ++q)  // position q takes rank (q * st) mod n
+	{
+		p[q] = tmp[r];
+		r += st;
+		r = r >= n ? r - n : r;
+	}
+}
+}  // namespace
+
 extern "C" {
 
 // Bucketing + packing on the device (ebo_bucket.inc).  d_raw: ebo_event[] on the device,
@@ -583,7 +605,7 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 			const Unit& u = units[static_cast<size_t>(w) * (P + 1) + b];
 			if (u.n_ev >= 2 && u.n_ev <= 8192)
 			{
-				std::sort(c->h_packed.begin() + u.ev_off, c->h_packed.begin() + u.ev_off + u.n_ev);
+				canonical_order(c->h_packed.data() + u.ev_off, u.n_ev);
 			}
 		}
 		base += n;
@@ -722,8 +744,7 @@ int ebo_set_patches(ebo_ctx* c, const ebo_event* ev, const size_t* offsets, cons
 		// the same patch inside a window
 		if (n >= 2 && n <= 8192 && !ab_env("EBO_KEEP_ORDER"))  // (A/B build: the list order, for the reference-order diagnostic)
 		{
-			std::sort(c->h_packed.begin() + static_cast<std::ptrdiff_t>(base),
-					  c->h_packed.begin() + static_cast<std::ptrdiff_t>(base + n));
+			canonical_order(c->h_packed.data() + base, static_cast<uint32_t>(n));
 		}
 		utmin[p] = tlo;
 		utmax[p] = thi;
