@@ -1,15 +1,17 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of a round on one MI355X (run through gpurun from the repo root):
-#   bash event-based-odomety_amd/tools/profile_round.sh r03
+#   bash event-based-odomety_amd/tools/profile_round.sh r04
 # Writes summaries under gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
 # Counter passes are separate runs (--pmc never together with traces), the program itself follows `--`.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 PY=python3
+# the SHIPPED library for every tool (tools/ab_*.py default to the -DEBO_AB build, whose kernels carry the diagnostics)
+export EBO_LIB_PATH=$R/event-based-odomety_amd/libebo_hip.so
 S="$PY $R/event-based-odomety_amd/tools/pmc_summary.py"
 
 # 1. kernel stats of the timed region of the bench (the dominant kernel's average launch duration)
@@ -23,7 +25,7 @@ cp $O/ks_full/*/*kernel_stats.csv $O/${TAG}_bench_full_kernel_stats.csv 2>/dev/n
 echo "[2/6] bench full done"
 
 # 3. counters of the dominant kernel at the shipping configuration (C3 x 64 windows)
-B="$PY $R/bench.py --no-extras --steps 5 --warmup 1 --cpu-seconds 1"
+B="$PY $R/bench.py --no-extras --steps 5 --warmup 1 --preheat 0 --cpu-seconds 1"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU -d $O/e3a --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT -d $O/e3b --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/e3c --output-format csv -- $B > /dev/null 2>&1
@@ -54,7 +56,7 @@ done
 echo "[5/6] count kernels done"
 
 # 5b. the N > 1 default workload's kernel (k_solve_independent, config-4 shard of one GPU) at N = 1: kernel stats + HBM traffic
-C4="$PY $R/bench.py --workload c4 --steps 5 --warmup 1 --cpu-seconds 1"
+C4="$PY $R/bench.py --workload c4 --steps 5 --warmup 1 --preheat 0 --cpu-seconds 1"
 rocprofv3 --kernel-trace --stats -d $O/ks_c4 --output-format csv -- $C4 > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
 cp $O/ks_c4/*/*kernel_stats.csv $O/${TAG}_bench_c4_1gpu_kernel_stats.csv 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $O/c4f --output-format csv -- $C4 > /dev/null 2>&1
