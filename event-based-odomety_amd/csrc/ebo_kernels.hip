@@ -3694,6 +3694,17 @@ int launch_count_image(const CountLaunch& L, void* stream)
 		}
 		// eligibility as before the finer splits existed: the coarsest split the LDS allows must already
 		// give the launch 64 workgroups (single windows and tiny batches stay with impl 0 / 1)
+		// (A/B build: force the tile pitch, e.g. whole patch rows / columns)
+		if (const size_t fw = ab_size("EBO_COUNT_TILE_W", 0), fh = ab_size("EBO_COUNT_TILE_H", 0); fw > 0 && fh > 0)
+		{
+			bestW = static_cast<int>(fw);
+			bestH = static_cast<int>(fh);
+			bestX = (W + bestW - 1) / bestW;
+			bestY = (H + bestH - 1) / bestH;
+			// the last tile of a row / column takes what is left: size the counters for the largest tile
+			const int lastW = W - (bestX - 1) * bestW, lastH = H - (bestY - 1) * bestH;
+			bestBytes = (static_cast<size_t>(std::max(bestW, lastW) + 1) * std::max(bestH, lastH) * b + 15) & ~size_t(15);
+		}
 		const long coarse = static_cast<long>(L.n_windows) * coarseTiles;
 		if (bestX > 0 && (L.impl == 5 || (coarseTiles > 1 && coarse >= 64)))
 		{

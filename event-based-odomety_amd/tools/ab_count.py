@@ -16,7 +16,7 @@ synth = importlib.import_module("event-based-odomety_amd.synth")
 if os.environ.get("AB_LIB"):  # A/B of two builds on the same box
     ebo.LIB_PATH = os.path.join(os.path.dirname(ebo.LIB_PATH), os.environ["AB_LIB"])
 
-KEYS = ("EBO_COUNT_IMPL", "EBO_COUNT_LDS_KB", "EBO_COUNT_BLOCK")
+KEYS = ("EBO_COUNT_IMPL", "EBO_COUNT_LDS_KB", "EBO_COUNT_BLOCK", "EBO_COUNT_TILE_W", "EBO_COUNT_TILE_H")
 
 
 def main():
