@@ -51,6 +51,27 @@ for order in ORDERS:
                     n = len(sel)
                     if order.startswith("permuted"):
                         key = base[np.random.default_rng(p + 1000 * w).permutation(n)]
+                    elif order.startswith("spatial"):
+                        # ranks by position (row-major, column-major or Morton), then dealt out with stride 127
+                        kind = order.split()[1]
+                        xs, ys = sel["x"].astype(np.int64) - rects[p][0], sel["y"].astype(np.int64) - rects[p][1]
+                        if kind == "rows":
+                            base2 = np.lexsort((dt.astype(np.uint32), xs, ys))
+                        elif kind == "cols":
+                            base2 = np.lexsort((dt.astype(np.uint32), ys, xs))
+                        else:
+                            def spread(v):
+                                v = v & 0xFF
+                                v = (v | (v << 4)) & 0x0F0F
+                                v = (v | (v << 2)) & 0x3333
+                                v = (v | (v << 1)) & 0x5555
+                                return v
+                            base2 = np.lexsort((dt.astype(np.uint32), spread(xs) | (spread(ys) << 1)))
+                        st = int(order.split()[2]) if len(order.split()) > 2 else 127
+                        st = max(st % max(n, 1), 1)
+                        while np.gcd(st, n) != 1:
+                            st += 1
+                        key = base2[(np.arange(n) * st) % n]
                     elif order.startswith("stride"):
                         what = order.split()[1]
                         st = {"golden": int(round(n * 0.6180339887)), "n/64+1": n // 64 + 1, "n/128+1": n // 128 + 1,
@@ -97,4 +118,18 @@ for order in ORDERS:
     torch.cuda.synchronize()
     print("%-34s %s x %d windows: %.4f ms per value+Jacobian evaluation, checksum %.6e"
           % (order, cfg["name"], Wn, e0.elapsed_time(e1) / 50, float(d_out[:, 0].sum())))
+    if os.environ.get("AB_SOLVE"):
+        d_sol = torch.zeros((Wn * P, 2), dtype=torch.float64, device="cuda")
+        d_stats = torch.zeros((Wn * P, 4), dtype=torch.int32, device="cuda")
+        opts = ebo.default_solver(mode=ebo.SOLVE_INDEPENDENT)
+        ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(3):
+            ctx.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        st = d_stats.cpu().numpy()
+        print("%-34s     device solve %.3f ms, evaluations %d (cost) + %d (Jacobian), flow checksum %.9e"
+              % ("", e0.elapsed_time(e1) / 3, int(st[:, 1].sum()), int(st[:, 2].sum()), float(d_sol.abs().sum())))
     ctx.close()
