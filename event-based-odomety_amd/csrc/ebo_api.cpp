@@ -366,24 +366,24 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 		// facade, the ranks of a rehearsal); a failed allocation is not an error (the reverse pass
 		// re-derives what the table would have held); and a context that kept a large table for one
 		// big batch gives it back when the batches that follow need less than a quarter of it.
-		size_t limit = env_size("EBO_EDGE_CS_MB", 4096) << 20;
-		size_t freeB = 0, totalB = 0;
-		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
-		{
-			limit = std::min(limit, (freeB + c->edge_cs_cap) / 4);
-		}
+		const size_t limit = env_size("EBO_EDGE_CS_MB", 4096) << 20;
 		if (L.want_jac && L.flow_sets == 1 && need <= limit && need > 0)
 		{
+			// (the free-memory probe and the allocation happen only when the table has to change size -- once per
+			// batch shape, never per launch: hipFree synchronises the whole device)
 			if (need > c->edge_cs_cap || need < c->edge_cs_cap / 4)
 			{
+				size_t freeB = 0, totalB = 0;
+				const bool probed = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
 				if (c->d_edge_cs)
 				{
 					c->hip(hipStreamSynchronize(c->stream), "sync");
 					hipFree(c->d_edge_cs);
 					c->d_edge_cs = nullptr;
+					freeB += c->edge_cs_cap;
 					c->edge_cs_cap = 0;
 				}
-				if (hipMalloc(reinterpret_cast<void**>(&c->d_edge_cs), need) == hipSuccess)
+				if ((!probed || need <= freeB / 4) && hipMalloc(reinterpret_cast<void**>(&c->d_edge_cs), need) == hipSuccess)
 				{
 					c->edge_cs_cap = need;
 				}
