@@ -603,7 +603,7 @@ static int set_windows_host(ebo_ctx* c, const ebo_event* ev, const size_t* offse
 		for (int b = 0; b <= P; ++b)
 		{
 			const Unit& u = units[static_cast<size_t>(w) * (P + 1) + b];
-			if (u.n_ev >= 2 && u.n_ev <= 8192)
+			if (u.n_ev >= 2 && u.n_ev <= 8192 && !ab_env("EBO_KEEP_ORDER"))  // (A/B build: list order, for the reference-order diagnostic)
 			{
 				canonical_order(c->h_packed.data() + u.ev_off, u.n_ev);
 			}
