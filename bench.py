@@ -326,7 +326,7 @@ class EboComm:
 
     def attach(self, ctx):
         cid = self.ebo.comm_unique_id() if self.rank == 0 else None
-        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid)
+        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid, timeout=900.0)  # rank 0 arrives after its CPU baseline
         ctx.comm_init(cid, self.rank, self.world)
         self.ctx = ctx
         self.d_one = self.torch.zeros(1, dtype=self.torch.float64, device="cuda")
@@ -501,7 +501,7 @@ def main():
                 if not ok:
                     raise SystemExit("--comm ebo: the library's communicator failed on rank %d: %s" % (rank, why))
                 return cand
-            if exchange.agree(cand.prefix, rank, world, ok):
+            if exchange.agree(cand.prefix, rank, world, ok, timeout=900.0):
                 return cand
             comm_notes["fallback"] = "the library's communicator could not be set up on every rank (%s): torch.distributed" % (why,)
             try:
