@@ -1471,6 +1471,18 @@ void ebo_destroy(ebo_ctx* c)
 		return;
 	}
 	(void)hipSetDevice(c->prm.device);
+	if (c->capturing)
+	{
+		// a context destroyed with a recording still open: end it first (a synchronisation inside a recording
+		// would leave the stream unusable for the rest of the process)
+		hipGraph_t g = nullptr;
+		if (hipStreamEndCapture(c->stream, &g) == hipSuccess && g)
+		{
+			(void)hipGraphDestroy(g);
+		}
+		(void)hipGetLastError();
+		c->capturing = false;
+	}
 	if (c->stream)
 	{
 		(void)hipStreamSynchronize(c->stream);

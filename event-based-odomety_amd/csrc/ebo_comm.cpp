@@ -131,6 +131,11 @@ int ebo_comm_init(ebo_ctx* c, const ebo_comm_id* id, int rank, int nranks)
 	c->comm_rank = rank;
 	c->comm_size = nranks;
 	// the exchange's own small buffers, so that no collective path has to allocate before its first collective
+	// (a new communicator starts with an empty exchange buffer: its growth is a function of what THIS communicator's
+	// ranks have gathered, so that every rank holds the same capacity)
+	hipFree(c->d_comm_buf);
+	c->d_comm_buf = nullptr;
+	c->comm_buf_cap = 0;
 	hipFree(c->d_comm_cnt);
 	c->d_comm_cnt = nullptr;
 	if (c->pin_comm)
