@@ -69,6 +69,15 @@ struct DetectorParams
 	unsigned int compensateMinNumEvents = 100;
 	size_t maxPatches = 100;
 
+	// updatePatches(event) is the front end's per-event call; one optimisation launch per ready patch and event is
+	// what the device is worst at (100 patches x 6000 events: 762 ms per event against 19 ms as one chunk).  Patches do
+	// not interact and nothing outside reads them between two events, so the detector keeps the events and brings the
+	// patches up to date -- all of them in lock-step rounds, bit-equal to the per-event sequence -- when `eventBatch`
+	// events have gathered or when anything is read or changed (getPatches, getArchivedPatches, preExit, newImage,
+	// setPatches, setParams, getOptimizedFinalCosts, associatePatches, updateNumOfEvents).  A reference obtained from
+	// getPatches() is current at the time of that call.  0 or 1: every event at once, as the reference.
+	size_t eventBatch = 4096;
+
 	int device = 0;                 // HIP device ordinal
 	int loss = EBO_LOSS_EDGE;       // reference default; EBO_LOSS_VARIANCE = north-star objective
 	int grad = EBO_GRAD_JET;        // reference default (ceres::Jet)
@@ -109,6 +118,7 @@ class FeatureDetector
 	}
 	~FeatureDetector()
 	{
+		pending_.clear();  // events nobody asked the result of
 		tracked_.reset();
 		if (ctx_)
 		{
@@ -121,6 +131,7 @@ class FeatureDetector
 	// feature_detector.cpp:484-491
 	void preExit()
 	{
+		flushPatches();
 		for (const Patch& patch : tracked_->getPatches())
 		{
 			archivedPatches_.push_back(patch);
@@ -141,6 +152,7 @@ class FeatureDetector
 				 "install FrontEndHooks");
 			return;
 		}
+		flushPatches();
 		guarded([&] {
 			extractPatchesImpl(image);
 			// flowEstimator_->addImage / getFlowPatches (flow_estimator.cpp:16-85)
@@ -201,6 +213,7 @@ class FeatureDetector
 			fail(EBO_ERR_UNSUPPORTED, "extractPatches needs the detectFeatures and gradients hooks");
 			return;
 		}
+		flushPatches();
 		guarded([&] { extractPatchesImpl(image); });
 	}
 
@@ -216,15 +229,37 @@ class FeatureDetector
 		return hooks_.detectFeatures(image);
 	}
 
-	// feature_detector.cpp:585-619: the reference's per-event call
+	// feature_detector.cpp:585-619: the reference's per-event call (DetectorParams::eventBatch: the event is kept
+	// and the patches are brought up to date in chunks; every reader sees them current)
 	void updatePatches(const common::EventSample& event)
 	{
-		guarded([&] { tracked_->updatePatches(event); });
+		if (params_.eventBatch <= 1)
+		{
+			guarded([&] { tracked_->updatePatches(event); });
+			return;
+		}
+		pending_.push_back(event);
+		if (pending_.size() >= params_.eventBatch)
+		{
+			flushPatches();
+		}
 	}
 	// the same for a chunk of the stream: all patches advance in lock-step rounds, one launch per stage
 	// (tracked_patches.h); per patch the sequence of addEvent / optimize calls is the per-event one
 	void updatePatches(const std::vector<common::EventSample>& chunk)
 	{
+		flushPatches();
+		guarded([&] { tracked_->updatePatches(chunk); });
+	}
+	// brings the tracked patches up to the last event handed to updatePatches(event)
+	void flushPatches()
+	{
+		if (pending_.empty())
+		{
+			return;
+		}
+		std::vector<common::EventSample> chunk;
+		chunk.swap(pending_);
 		guarded([&] { tracked_->updatePatches(chunk); });
 	}
 
@@ -232,6 +267,7 @@ class FeatureDetector
 	// extractPatches); called without one (its own associatedPatchesTest does) the user count is skipped.
 	void associatePatches(Patches& newPatches, const common::timestamp_t& timestamp)
 	{
+		flushPatches();
 		Patches& patches = tracked_->getPatches();
 		for (auto& patch : patches)
 		{
@@ -269,19 +305,33 @@ class FeatureDetector
 	// feature_detector.cpp:666-711 (the estimate on the device against the latest frame's gradients)
 	void updateNumOfEvents(Patch& patch)
 	{
+		flushPatches();
 		guarded([&] { tracked_->updateNumOfEvents(patch); });
 	}
 
-	void setPatches(const Patches& patches) { tracked_->setPatches(patches); }  // feature_detector.h:67
+	void setPatches(const Patches& patches)  // feature_detector.h:67
+	{
+		flushPatches();
+		tracked_->setPatches(patches);
+	}
 	void setTrackId(TrackId trackId) { nextTrackId_ = static_cast<size_t>(trackId); }
-	Patches const& getPatches() const { return tracked_->getPatches(); }
-	Patches& getPatches() { return tracked_->getPatches(); }
+	Patches const& getPatches() const
+	{
+		const_cast<FeatureDetector*>(this)->flushPatches();  // (logically const: the events were handed over before)
+		return tracked_->getPatches();
+	}
+	Patches& getPatches()
+	{
+		flushPatches();
+		return tracked_->getPatches();
+	}
 	Corners const& getFeatures() const { return corners_; }
 	Patches const& getArchivedPatches() const { return archivedPatches_; }
 	// feature_detector.h:80-83: optimizers_.begin()->second->getFinalCosts() (undefined there when no
 	// optimizer exists; empty here).  optimizers_ is ordered by frame time here: begin() = oldest frame in use.
 	std::vector<tracker::OptimizerFinalLoss> getOptimizedFinalCosts() const
 	{
+		const_cast<FeatureDetector*>(this)->flushPatches();
 		const auto& optimizers = tracked_->optimizers();
 		if (optimizers.empty() || !optimizers.begin()->second)
 		{
@@ -292,6 +342,7 @@ class FeatureDetector
 	// optimizers_[image.timestamp.count()] for callers that bring patches in through setPatches
 	void setOptimizer(const common::timestamp_t& initTime, std::shared_ptr<Optimizer> optimizer)
 	{
+		flushPatches();
 		tracked_->setOptimizer(initTime, std::move(optimizer));
 	}
 	// gradX_ / gradY_ (:554-555) for callers that do not go through newImage
@@ -299,7 +350,11 @@ class FeatureDetector
 	{
 		guarded([&] { tracked_->setGradients(gradX, gradY); });
 	}
-	TrackedPatches& tracked() { return *tracked_; }
+	TrackedPatches& tracked()
+	{
+		flushPatches();
+		return *tracked_;
+	}
 
 	// feature_detector.cpp:621-628
 	void addEvent(const common::EventSample& event)
@@ -462,6 +517,7 @@ class FeatureDetector
 	// The device context is re-created when a field it was built from changed.
 	void setParams(const tracker::DetectorParams& params)
 	{
+		flushPatches();
 		const bool rebuild = params.imageSize.width != params_.imageSize.width ||
 							 params.imageSize.height != params_.imageSize.height ||
 							 params.patchCompensateSize.width != params_.patchCompensateSize.width ||
@@ -670,6 +726,7 @@ class FeatureDetector
 	DetectorParams params_;
 	FrontEndHooks hooks_;
 	std::unique_ptr<TrackedPatches> tracked_;
+	std::vector<common::EventSample> pending_;  // handed to updatePatches(event), not yet routed (eventBatch)
 	Corners corners_;
 	size_t nextTrackId_ = 0;
 	Patches archivedPatches_;

@@ -253,8 +253,6 @@ class TrackedPatches
 		{
 			return;
 		}
-		const std::vector<ebo_event> ev = common::toEboEvents(chunk);
-		check(ebo_route_set_events(ctx_, ev.data(), n));
 		const size_t np = patches_.size();
 		std::vector<Patch*> at;  // patches_ is a list (the reference's type): index it once
 		at.reserve(np);
@@ -286,6 +284,12 @@ class TrackedPatches
 			live.push_back(static_cast<int>(i));
 		}
 		rounds_ = 0;
+		if (live.empty())
+		{
+			return;  // nothing is being tracked yet: the patches only collected events, the device was not needed
+		}
+		const std::vector<ebo_event> ev = common::toEboEvents(chunk);
+		check(ebo_route_set_events(ctx_, ev.data(), n));
 		std::vector<double> rects;
 		std::vector<uint32_t> start, take, index, count, next;
 		while (!live.empty())

@@ -20,6 +20,7 @@
 //   * newImage without hooks reports EBO_ERR_UNSUPPORTED through the error policy.
 // `--cpu` runs the host-only subset (no device): the two reference tests' bookkeeping and the error policy.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -550,6 +551,36 @@ int main(int argc, char** argv)
 		for (size_t i = 0; i < one.size(); ++i)
 		{
 			EXPECT_TRUE(samePatch(nth(one, i), nth(chunked.getPatches(), i)));
+		}
+
+		// DetectorParams::eventBatch: the per-event call keeps the events and routes them in chunks (the loop above ran
+		// that way: the evaluator's DetectorParams are the defaults); with eventBatch = 1 every event is processed at
+		// once, as the reference does -- the same patches either way, and the time it takes
+		{
+			tracker::DetectorParams immediate, deferred;
+			immediate.eventBatch = 1;
+			tracker::FeatureDetector a(immediate), b(deferred);
+			installTracked(a, W, H);
+			installTracked(b, W, H);
+			const auto t0 = std::chrono::steady_clock::now();
+			for (size_t i = 0; i < 5000; ++i)
+			{
+				a.updatePatches(stream[i]);
+			}
+			const auto t1 = std::chrono::steady_clock::now();
+			for (size_t i = 0; i < 5000; ++i)
+			{
+				b.updatePatches(stream[i]);
+			}
+			const tracker::Patches& pb = b.getPatches();  // brings them up to the last event
+			const auto t2 = std::chrono::steady_clock::now();
+			for (size_t i = 0; i < pb.size(); ++i)
+			{
+				EXPECT_TRUE(samePatch(nth(a.getPatches(), i), nth(pb, i)));
+			}
+			std::printf("updatePatches(event) x 5000, 6 patches: every event at once %.1f ms, kept and routed in chunks %.1f ms\n",
+						std::chrono::duration<double, std::milli>(t1 - t0).count(),
+						std::chrono::duration<double, std::milli>(t2 - t1).count());
 		}
 
 		// visual_odometry::Keyframe over the detector's patches (evaluator.cpp:85-87)
