@@ -84,6 +84,7 @@ def test_recorded_solve_and_count_image(ebo, synth):
         d_sol = torch.zeros((3 * c.P, 2), dtype=torch.float64, device="cuda")
         d_stats = torch.zeros((3 * c.P, 4), dtype=torch.int32, device="cuda")
         d_img = torch.zeros((3, 180, 240), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()  # the context launches on its own stream: the fills above must have landed
 
         def step():
             c.solve_device(opts, d_sol.data_ptr(), d_stats.data_ptr())

@@ -209,6 +209,7 @@ def test_band_limited_images_of_the_shards_assemble_the_whole_image(ebo, synth, 
         if b < e:
             my, sev, soffs = _shard_events(S, b, e, n_windows)
             c = ebo.Context(**S["kw"])
+            c.set_stream(torch.cuda.current_stream().cuda_stream)  # the buffers are torch's: one stream, no race with their fills
             c.set_patches(sev, soffs, np.tile(S["rects"][my], (n_windows, 1)))
             ptr = lambda t: t.data_ptr() if t is not None else 0
             c.count_image_band_device(n_windows, S["t_ref"], d_flows.data_ptr(), band, ptr(R["top"]), ptr(R["own"]),
@@ -250,3 +251,94 @@ def test_band_limited_images_of_the_shards_assemble_the_whole_image(ebo, synth, 
         if R["ctx"] is not None:
             R["ctx"].close()
     assert S["whole"].sum() > 0.5 * sum(len(e) for e in S["evs"])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_band_limited_images_on_random_geometries(ebo, seed):
+    """The band-limited image against the one-process image on random sensors, grids, shard counts, halos, window
+    counts and flows (seeded): whenever no rank raises the flag, own rows + received halos assemble the whole image bit
+    for bit; when a rank raises it, an event really could leave its band (the dense sum is still right)."""
+    import torch
+    rng = np.random.RandomState(1000 + seed)
+    iw, ih = int(rng.randint(40, 400)), int(rng.randint(40, 300))
+    pw, ph = int(rng.randint(8, 48)), int(rng.randint(8, 40))
+    pw, ph = min(pw, iw), min(ph, ih)
+    n_windows = int(rng.randint(1, 4))
+    n = int(rng.choice([500, 5000, 40000]))
+    dur = int(rng.choice([5000, 50000]))
+    evs, offs = [], [0]
+    for w in range(n_windows):
+        t = np.sort(rng.randint(0, dur, n)) + 1_000_000 + w * dur
+        x = rng.randint(-4 if seed % 3 == 0 else 0, iw + (4 if seed % 3 == 0 else 0), n)
+        y = rng.randint(-4 if seed % 3 == 0 else 0, ih + (4 if seed % 3 == 0 else 0), n)
+        evs.append(ebo.make_events(x.astype(np.int32), y.astype(np.int32), t.astype(np.int64), np.where(rng.rand(n) < 0.5, 1, -1).astype(np.int32)))
+        offs.append(offs[-1] + n)
+    allev = np.concatenate(evs)
+    kw = dict(image_w=iw, image_h=ih, patch_w=pw, patch_h=ph, loss=ebo.LOSS_VARIANCE, tv_weight=0.0,
+              max_events=len(allev), max_windows=n_windows)
+    with ebo.Context(**kw) as c:
+        c.set_windows(allev, offs)
+        npx, npy, P = c.npx, c.npy, c.P
+        amp = float(rng.choice([0.0, 0.3, 1.0, 4.0]))
+        flows = rng.uniform(-amp, amp, (n_windows, P, 2))
+        whole = c.count_image(ebo.COUNT_WARPED, flows)
+        rects = np.array([c.patch_rect(p % npx, p // npx) for p in range(P)])
+        t_ref = [c.window_info(w)[0] for w in range(n_windows)]
+    world = int(rng.randint(1, min(npy, 8) + 1))
+    bounds = [int(rects[ebo.shard_range(npy, r, world)[0] * npx][1]) if ebo.shard_range(npy, r, world)[0] < npy else ih
+              for r in range(world)] + [ih]
+    bounds[0] = 0
+    halo = int(rng.randint(0, 40))
+    try:
+        bands = [ebo.band_plan(ih, bounds, r, halo) for r in range(world)]
+    except ebo.EboError as err:
+        assert err.code == ebo.ERR_UNSUPPORTED  # a halo larger than a neighbour: the same verdict for every rank
+        return
+    S = dict(evs=evs, npx=npx, npy=npy, pw=pw, ph=ph)
+    d_flows = torch.from_numpy(flows).to("cuda")
+    ranks = []
+    for r in range(world):
+        b, e = ebo.shard_range(npy, r, world)
+        band = bands[r]
+        mk = lambda rows: torch.full((n_windows, rows, iw), -3, dtype=torch.int32, device="cuda") if rows else None
+        R = dict(band=band, top=mk(band.top_rows), own=mk(band.own_rows), bottom=mk(band.bottom_rows),
+                 flag=torch.zeros(1, dtype=torch.int32, device="cuda"), ctx=None)
+        if b < e:
+            my, sev, soffs = _shard_events(S, b, e, n_windows)
+            c = ebo.Context(**kw)
+            c.set_stream(torch.cuda.current_stream().cuda_stream)  # the buffers are torch's: one stream, no race with their fills
+            c.set_patches(sev, soffs, np.tile(rects[my], (n_windows, 1)))
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            c.count_image_band_device(n_windows, t_ref, d_flows.data_ptr(), band, ptr(R["top"]), ptr(R["own"]), ptr(R["bottom"]),
+                                      R["flag"].data_ptr())
+            c.synchronize()
+            R["ctx"] = c
+        ranks.append(R)
+    torch.cuda.synchronize()
+    escaped = max(int(R["flag"].item()) for R in ranks)
+    if not escaped:
+        rows = []
+        for r, R in enumerate(ranks):
+            band = R["band"]
+            if R["ctx"] is None:
+                continue
+            above = ranks[r - 1]["bottom"] if r > 0 and band.recv_above else None
+            below = ranks[r + 1]["top"] if r + 1 < world and band.recv_below else None
+            assert (above.shape[1] if above is not None else 0) == band.recv_above
+            assert (below.shape[1] if below is not None else 0) == band.recv_below
+            img = torch.zeros((n_windows, band.own_rows, iw), dtype=torch.float64, device="cuda")
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            R["ctx"].band_finish_device(n_windows, band, ptr(R["own"]), ptr(above), ptr(below), img.data_ptr())
+            R["ctx"].synchronize()
+            rows.append(img.cpu().numpy())
+        assert np.array_equal(np.concatenate(rows, axis=1), whole)
+    else:
+        assert amp * dur * 0.5e-3 + 1 > halo or any(R["band"].own_rows == 0 for R in ranks) or seed % 3 == 0
+        total = np.zeros_like(whole)
+        for R in ranks:
+            if R["ctx"] is not None:
+                total += R["ctx"].count_image_shard(n_windows, t_ref, flows)
+        assert np.array_equal(total, whole)
+    for R in ranks:
+        if R["ctx"] is not None:
+            R["ctx"].close()
