@@ -207,6 +207,81 @@ __global__ void __launch_bounds__(256) k_tensor_valu(const double* __restrict__ 
 	}
 }
 
+// (c) what sharing through LDS would buy if the LDS were there: products of the differences once per pixel, horizontally
+// filtered rows once per pixel (both staged in LDS: 24 + 24 B per pixel of the region and its halo), then the vertical pass.
+// 133 KB of LDS for one 64 x 64 canvas: NOT available to k_eval_edge (its two-per-CU layout has 77 KB per unit in all).
+__global__ void __launch_bounds__(256) k_tensor_shared(const double* __restrict__ image, double* __restrict__ E, long long* __restrict__ clk,
+														 int reps, double hs)
+{
+	extern __shared__ double sh[];
+	double* I = sh;                         // kN * kPitch
+	constexpr int kH = kRegion + 6;         // rows / columns of the halo region
+	double* P = I + kN * kPitch;            // 3 x kH x (kH + 1)
+	double* Hh = P + 3 * kH * (kH + 1);     // 3 x kH x kRegion
+	for (int p = threadIdx.x; p < kN * kN; p += blockDim.x)
+	{
+		I[(p / kN) * kPitch + p % kN] = image[p];
+	}
+	double e[4];
+	for (int k = 0; k < 4; ++k)
+	{
+		e[k] = exp(hs * k * k);
+	}
+	__syncthreads();
+	const long long t0 = clock64();
+	for (int rep = 0; rep < reps; ++rep)
+	{
+		for (int k = threadIdx.x; k < kH * kH; k += blockDim.x)
+		{
+			const int yy = kR0 - 3 + k / kH, xx = kR0 - 3 + k % kH;
+			const double c0 = I[yy * kPitch + xx], gx = I[yy * kPitch + xx + 1] - c0, gy = I[(yy + 1) * kPitch + xx] - c0;
+			double* q = P + (k / kH) * (kH + 1) + k % kH;
+			q[0] = gx * gx;
+			q[kH * (kH + 1)] = gx * gy;
+			q[2 * kH * (kH + 1)] = gy * gy;
+		}
+		__syncthreads();
+		for (int k = threadIdx.x; k < kH * kRegion; k += blockDim.x)
+		{
+			const int r = k / kRegion, x = k % kRegion;
+#pragma unroll
+			for (int c = 0; c < 3; ++c)
+			{
+				const double* q = P + c * kH * (kH + 1) + r * (kH + 1) + x;
+				double h = e[0] * q[3];
+				h = fma(e[1], q[2] + q[4], h);
+				h = fma(e[2], q[1] + q[5], h);
+				h = fma(e[3], q[0] + q[6], h);
+				Hh[c * kH * kRegion + k] = h;
+			}
+		}
+		__syncthreads();
+		for (int k = threadIdx.x; k < kRegion * kRegion; k += blockDim.x)
+		{
+			const int y = k / kRegion, x = k % kRegion;
+			double s[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c)
+			{
+				const double* q = Hh + c * kH * kRegion + y * kRegion + x;
+				double v = e[0] * q[3 * kRegion];
+				v = fma(e[1], q[2 * kRegion] + q[4 * kRegion], v);
+				v = fma(e[2], q[1 * kRegion] + q[5 * kRegion], v);
+				v = fma(e[3], q[0] + q[6 * kRegion], v);
+				s[c] = v;
+			}
+			const double tr = s[0] + s[2], det = s[0] * s[2] - s[1] * s[1];
+			E[(kR0 + y) * kN + kR0 + x] = 0.5 * (tr + sqrt(tr * tr - 4.0 * det));
+		}
+		__syncthreads();
+	}
+	const long long t1 = clock64();
+	if (threadIdx.x == 0)
+	{
+		clk[blockIdx.x] = t1 - t0;
+	}
+}
+
 int main()
 {
 	const double hs = -0.5 / (1.5 * 1.5);
@@ -271,6 +346,15 @@ int main()
 		hipLaunchKernelGGL(k_tensor_valu, dim3(blocks), dim3(256), 0, 0, d_img, d_E, d_clk, 20, hs);
 		hipDeviceSynchronize();
 		if (pass) report("VALU 8-row runs", 20);
+		{
+			constexpr int kH = kRegion + 6;
+			const size_t lds = (kN * kPitch + 3 * kH * (kH + 1) + 3 * kH * kRegion) * sizeof(double);
+			hipFuncSetAttribute(reinterpret_cast<const void*>(k_tensor_shared), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+			hipMemset(d_E, 0, img.size() * 8);
+			hipLaunchKernelGGL(k_tensor_shared, dim3(blocks), dim3(256), lds, 0, d_img, d_E, d_clk, 20, hs);
+			hipDeviceSynchronize();
+			if (pass) report("VALU, LDS-shared", 20);
+		}
 	}
 	hipLaunchKernelGGL(k_mfma_rate, dim3(blocks), dim3(256), 0, 0, d_sink, d_clk, 1000);
 	hipDeviceSynchronize();
