@@ -16,8 +16,22 @@
 
 #include "../../../include/ebo.h"
 
+// With OpenCV on the include path the OpenCV value types ARE the reference's types (common/include/common/geometry.h,
+// data_types.h:39): the stand-ins below give way to them, so that code written against the reference -- cv::Point2i in
+// an Event, cv::Mat in an ImageSample -- compiles without a rename.
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#define EBO_HAVE_OPENCV 1
+#endif
+#endif
+
 namespace common
 {
+#ifdef EBO_HAVE_OPENCV
+using Point2i = cv::Point2i;
+using Point2d = cv::Point2d;
+#else
 // cv::Point2i stand-in (two ints, x then y).
 struct Point2i
 {
@@ -34,6 +48,7 @@ struct Point2d
 	Point2d() = default;
 	Point2d(double x_, double y_) : x(x_), y(y_) {}
 };
+#endif
 
 using timestamp_t = std::chrono::microseconds;
 
@@ -92,6 +107,9 @@ struct Event
 
 // CV_8U single-channel cv::Mat stand-in: what ImageSample carries to FeatureDetector::newImage
 // (data_types.h:39).  The event-warping path never reads pixels; the front-end hooks do.
+#ifdef EBO_HAVE_OPENCV
+using Image8 = cv::Mat;
+#else
 struct Image8
 {
 	int rows = 0;
@@ -100,6 +118,7 @@ struct Image8
 	Image8() = default;
 	Image8(int r, int c) : rows(r), cols(c), data(static_cast<size_t>(r) * c, 0) {}
 };
+#endif
 
 using EventSample = Sample<Event>;
 using ImageSample = Sample<Image8>;

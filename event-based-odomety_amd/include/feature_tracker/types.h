@@ -13,6 +13,22 @@
 
 namespace tracker
 {
+#ifdef EBO_HAVE_OPENCV
+// OpenCV is there (common/data_types.h found <opencv2/core.hpp>): the reference's own types, no stand-ins.  Mat64 is a
+// cv::Mat of CV_64F with the two conveniences the facade's own code uses, so a `Mat64 const&` IS a `cv::Mat const&`
+// (tools::Evaluator::getCompensatedEventImage returns one unchanged).
+using Size = cv::Size;
+using Rect2i = cv::Rect2i;
+using Rect2d = cv::Rect2d;
+class Mat64 : public cv::Mat
+{
+   public:
+	Mat64() = default;
+	Mat64(int r, int c) : cv::Mat(cv::Mat::zeros(r, c, CV_64F)) {}
+	double* ptr() { return cv::Mat::ptr<double>(0); }
+	const double* ptr() const { return cv::Mat::ptr<double>(0); }
+};
+#else
 struct Size
 {
 	int width = 0;
@@ -70,6 +86,8 @@ class Mat64
    private:
 	std::vector<double> data_;
 };
+
+#endif
 
 using Corner = common::Point2d;        // patch.h:10
 using Corners = std::vector<Corner>;   // patch.h:11

@@ -94,11 +94,25 @@ Keyframe::Keyframe(const tracker::Patches& patches,
 }
 }  // namespace visual_odometry
 
+// Two flavours of this program: without OpenCV on the include path the shell below spells the two OpenCV types of the
+// evaluator's interface with the facade's stand-ins; built with -Istubs_opencv (test-only declarations of cv::Size_,
+// cv::Point_, cv::Rect_, cv::Mat) the facade's EBO_HAVE_OPENCV branch is live and the shell keeps the reference's own
+// `cv::Size2i imageSize` and `cv::Mat const& getCompensatedEventImage()` -- no rename at all.
+#ifdef EBO_HAVE_OPENCV
+using EvaluatorSize = cv::Size2i;
+using EvaluatorImage = cv::Mat;
+static common::Image8 makeImage8(int rows, int cols) { return cv::Mat(rows, cols, CV_8U); }
+#else
+using EvaluatorSize = tracker::Size;
+using EvaluatorImage = tracker::Mat64;
+static common::Image8 makeImage8(int rows, int cols) { return common::Image8(rows, cols); }
+#endif
+
 namespace tools
 {
-struct EvaluatorParams  // tools/evaluator/include/evaluator/evaluator.h:14-26 (cv::Size2i -> tracker::Size)
+struct EvaluatorParams  // tools/evaluator/include/evaluator/evaluator.h:14-26
 {
-	tracker::Size imageSize = {240, 180};
+	EvaluatorSize imageSize = {240, 180};
 	std::string outputDir = "/tmp";
 	bool drawImages = false;
 	// compensate whole image each k microseconds
@@ -119,8 +133,8 @@ class Evaluator  // evaluator.h:28-88, the members the tracker side touches
 	void saveFeaturesTrajectory(const tracker::Patches& patches);
 	void saveFinalCosts(const std::vector<tracker::OptimizerFinalLoss>& vectorFinalCosts);
 	tracker::Patches const& getPatches() const;
-	tracker::Mat64 const& getCompensatedEventImage();
-	tracker::Mat64 const& getIntegratedEventImage();
+	EvaluatorImage const& getCompensatedEventImage();
+	EvaluatorImage const& getIntegratedEventImage();
 	tracker::FeatureDetector& tracker() { return *tracker_; }  // test access
 	int windows = 0;                                           // test instrumentation
 
@@ -206,13 +220,13 @@ void Evaluator::saveFinalCosts(const std::vector<tracker::OptimizerFinalLoss>& v
 	costFile.close();
 }
 
-// ---- evaluator.cpp:219-227, verbatim (cv::Mat -> tracker::Mat64) -----------------------------------
-tracker::Mat64 const& Evaluator::getCompensatedEventImage()
+// ---- evaluator.cpp:219-227, verbatim (EvaluatorImage = cv::Mat with OpenCV) -------------------------
+EvaluatorImage const& Evaluator::getCompensatedEventImage()
 {
 	return tracker_->getCompensatedEventImage();
 }
 
-tracker::Mat64 const& Evaluator::getIntegratedEventImage()
+EvaluatorImage const& Evaluator::getIntegratedEventImage()
 {
 	return tracker_->getIntegratedEventImage();
 }
@@ -317,10 +331,15 @@ static auto nth(L& l, size_t i) -> decltype(*l.begin())
 	return *std::next(l.begin(), static_cast<std::ptrdiff_t>(i));
 }
 
-static bool sameImage(const tracker::Mat64& a, const tracker::Mat64& b)
+static const double* pixels(const tracker::Mat64& m) { return m.ptr(); }
+#ifdef EBO_HAVE_OPENCV
+static const double* pixels(const cv::Mat& m) { return m.ptr<double>(0); }
+#endif
+template <class A, class B>
+static bool sameImage(const A& a, const B& b)
 {
 	return a.rows == b.rows && a.cols == b.cols &&
-		   std::memcmp(a.ptr(), b.ptr(), sizeof(double) * static_cast<size_t>(a.rows) * a.cols) == 0;
+		   std::memcmp(pixels(a), pixels(b), sizeof(double) * static_cast<size_t>(a.rows) * a.cols) == 0;
 }
 
 static bool samePatch(const tracker::Patch& p, const tracker::Patch& q)
@@ -453,7 +472,7 @@ static int hostOnly()
 		tracker::DetectorParams params;
 		params.errorPolicy = tracker::DetectorParams::ERRORS_STATUS;
 		tracker::FeatureDetector detector(params);
-		common::ImageSample image(common::Image8(180, 240), common::timestamp_t(5));
+		common::ImageSample image(makeImage8(180, 240), common::timestamp_t(5));
 		detector.newImage(image);
 		EXPECT_TRUE(detector.status() == EBO_ERR_UNSUPPORTED);
 		EXPECT_TRUE(detector.detectFeatures(image.value).empty() && detector.status() == EBO_ERR_UNSUPPORTED);
@@ -597,7 +616,7 @@ int main(int argc, char** argv)
 		evaluator.setTrackerParams(np);
 		EXPECT_TRUE(evaluator.tracker().getEvents().empty() && evaluator.tracker().getLastCompensation().count() == 0);
 		EXPECT_TRUE(optOne->getParams()->maxNumIterations == 3);
-		EXPECT_TRUE(evaluator.getCompensatedEventImage().at<double>(90, 120) == 0.0);
+		EXPECT_TRUE(evaluator.getCompensatedEventImage().template at<double>(90, 120) == 0.0);
 		for (int i = 0; i < 5200; ++i)
 		{
 			evaluator.tracker().addEvent(stream[i]);
@@ -651,7 +670,7 @@ int main(int argc, char** argv)
 			return !(x < 10.f);
 		};
 		detector.setFrontEndHooks(hooks);
-		common::ImageSample first(common::Image8(H, W), common::timestamp_t(1000));
+		common::ImageSample first(makeImage8(H, W), common::timestamp_t(1000));
 		detector.newImage(first);
 		EXPECT_TRUE(detector.getFeatures().size() == 5 && detector.getPatches().size() == 5);
 		EXPECT_TRUE(detector.tracked().optimizers().size() == 1);
@@ -660,7 +679,7 @@ int main(int argc, char** argv)
 			EXPECT_TRUE(!p.isInit() && !p.isLost() && p.getTrajectory().size() == 1);  // one image: no flow yet
 		}
 		shift = 1.0;
-		common::ImageSample second(common::Image8(H, W), common::timestamp_t(41000));
+		common::ImageSample second(makeImage8(H, W), common::timestamp_t(41000));
 		detector.newImage(second);
 		// the four blobs are re-detected 1 px away (associated, no new track); (7,100) has no flow: lost and
 		// archived, its frame's optimizer loses a user; (200,30) is new: track id 5 on the second frame's optimizer
@@ -708,7 +727,7 @@ int main(int argc, char** argv)
 	{
 		tracker::DetectorParams dp;
 		tracker::FeatureDetector detector(dp);
-		common::ImageSample image(common::Image8(H, W), common::timestamp_t(5));
+		common::ImageSample image(makeImage8(H, W), common::timestamp_t(5));
 		bool threw = false;
 		try
 		{

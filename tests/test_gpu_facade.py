@@ -111,3 +111,26 @@ def test_front_end_lines_run_like_the_pair(ebo):
     print(out.stdout[-4000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-4000:]
     assert "all passed" in out.stdout
+
+
+def test_front_end_lines_with_opencv_types_compile_and_host_subset(ebo):
+    """CPU: the facade's EBO_HAVE_OPENCV branch (common::Point2i = cv::Point2i, tracker::Size / Rect2i / Rect2d = the
+    cv:: types, Mat64 a cv::Mat of CV_64F, ImageSample = Sample<cv::Mat>) against test-only OpenCV declarations
+    (tests/cpp/stubs_opencv): the evaluator shell keeps `cv::Size2i imageSize` and `cv::Mat const&
+    getCompensatedEventImage()`, i.e. the reference's statements compile with no type renamed."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "front_end_lines_opencv_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+    run = subprocess.run([os.path.join(CPP, "front_end_lines_opencv_test"), "--cpu"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "all passed" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_front_end_lines_with_opencv_types_run_like_the_pair(ebo):
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "front_end_lines_opencv_test"])
+    out = subprocess.run([os.path.join(CPP, "front_end_lines_opencv_test")], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-4000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-4000:]
+    assert "all passed" in out.stdout
