@@ -13,6 +13,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
+import torch  # noqa: F401,E402  (its HIP runtime first, see tests/conftest.py)
+# the switches compared here exist only in the A/B build (make ab; csrc/ab_env.h)
+os.environ.setdefault("EBO_LIB_PATH", os.path.join(os.path.dirname(HERE), "event-based-odomety_amd", "libebo_hip_ab.so"))
 ebo = importlib.import_module("event-based-odomety_amd")
 import test_gpu_random as T  # noqa: E402
 
