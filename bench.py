@@ -406,8 +406,9 @@ def main():
     ap.add_argument("--workload", choices=("auto", "eval", "c4", "replicas"), default="auto")
     ap.add_argument("--config", type=int, default=3, help="eval / replicas: BASELINE config index (3 = configs[2])")
     ap.add_argument("--windows", type=int, default=None, help="eval / replicas: independent windows per GPU per step")
-    ap.add_argument("--c4-windows", type=int, default=8, help="c4: windows in flight PER GPU (batch = N x this); "
-                    "8 since round 3: one GPU's shard solves 4 / 8 / 16 / 32 windows in 1.89 / 1.60 / 1.48 / 1.46 ms per window")
+    ap.add_argument("--c4-windows", type=int, default=32, help="c4: windows in flight PER GPU (batch = N x this); "
+                    "32 since round 4: one GPU's shard solves 8 / 16 / 32 windows in 1.73 / 1.55 / 1.45 ms per window "
+                    "(8 192 units leave the chip's tail visible; 288 GB of HBM hold far more)")
     ap.add_argument("--strong", action="store_true", help="c4: keep the batch at --c4-windows windows in total")
     ap.add_argument("--no-c4-image", action="store_true", help="c4: stop the step at solve + all-gather (no final count image)")
     ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
