@@ -446,7 +446,7 @@ def main():
     if args.warmup is None:
         args.warmup = {"eval": 10, "c4": 2, "replicas": 3}[workload]
     if args.windows is None:
-        args.windows = 64 if args.config >= 3 else 256
+        args.windows = 128 if args.config >= 3 else 256  # (C3: 64 / 128 / 256 windows per launch = 26.1 / 27.2 / 27.3 Gev/s)
     extras_on = rank == 0 and world == 1 and not args.no_extras and workload == "eval"
 
     # N > 1: the CPU baseline of rank 0 runs BEFORE anything touches the GPU or the process group (the
