@@ -52,6 +52,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+T_START = time.time() - 2.0  # files of the id hand-over older than this run are somebody else's
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X spec: f64 vector FMA, 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
 # Useful f64 operations of one edge-loss evaluation per item of work (DESIGN.md 4.5 derives them from
@@ -326,7 +327,7 @@ class EboComm:
 
     def attach(self, ctx):
         cid = self.ebo.comm_unique_id() if self.rank == 0 else None
-        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid, timeout=900.0)  # rank 0 arrives after its CPU baseline
+        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid, timeout=900.0, not_before=T_START)  # rank 0 arrives after its CPU baseline
         ctx.comm_init(cid, self.rank, self.world)
         self.ctx = ctx
         self.d_one = self.torch.zeros(1, dtype=self.torch.float64, device="cuda")
@@ -502,7 +503,7 @@ def main():
                 if not ok:
                     raise SystemExit("--comm ebo: the library's communicator failed on rank %d: %s" % (rank, why))
                 return cand
-            if exchange.agree(cand.prefix, rank, world, ok, timeout=900.0):
+            if exchange.agree(cand.prefix, rank, world, ok, timeout=900.0, not_before=T_START):
                 return cand
             comm_notes["fallback"] = "the library's communicator could not be set up on every rank (%s): torch.distributed" % (why,)
             try:

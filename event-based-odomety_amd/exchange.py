@@ -101,13 +101,21 @@ def halo_exchange(top, bottom, from_above, from_below, flag, group=None):
     return flag
 
 
-def handover_bytes(prefix, rank, world, payload=None, timeout=120.0):
+def handover_bytes(prefix, rank, world, payload=None, timeout=120.0, not_before=None):
     """Rank 0's `payload` (bytes: the 128-byte id of ebo_comm_unique_id) on every rank of one node, through the
     file `prefix`.id written atomically by rank 0 -- no framework, no sockets.  Then every rank leaves a mark
-    (`prefix`.got.<rank>); rank 0 removes the files once all marks are there."""
+    (`prefix`.got.<rank>); rank 0 removes the files once all marks are there.  not_before (seconds since the epoch,
+    e.g. the time this process started): a file older than that is what a crashed earlier run left behind under the
+    same name and is ignored (rank 0 replaces it)."""
     import os
     import time
     path = prefix + ".id"
+
+    def fresh():
+        try:
+            return os.path.exists(path) and (not_before is None or os.path.getmtime(path) >= not_before)
+        except OSError:
+            return False
     if rank == 0:
         if payload is None:
             raise ValueError("rank 0 hands the payload over")
@@ -116,7 +124,7 @@ def handover_bytes(prefix, rank, world, payload=None, timeout=120.0):
             fp.write(payload)
         os.replace(tmp, path)
     t0 = time.time()
-    while not os.path.exists(path):
+    while not fresh():
         if time.time() - t0 > timeout:
             raise TimeoutError("no %s after %.0f s" % (path, timeout))
         time.sleep(0.01)
@@ -134,7 +142,7 @@ def handover_bytes(prefix, rank, world, payload=None, timeout=120.0):
     return got
 
 
-def agree(prefix, rank, world, ok, timeout=120.0):
+def agree(prefix, rank, world, ok, timeout=120.0, not_before=None):
     """Every rank's yes / no on every rank (files `prefix`.ok.<rank>): True when all said yes.  For decisions every
     rank must take the same way BEFORE any collective exists (does the library's communicator work here?)."""
     import os
@@ -148,7 +156,7 @@ def agree(prefix, rank, world, ok, timeout=120.0):
     votes = []
     for q in range(world):
         p = "%s.ok.%d" % (prefix, q)
-        while not os.path.exists(p):
+        while not (os.path.exists(p) and (not_before is None or os.path.getmtime(p) >= not_before)):
             if time.time() - t0 > timeout:
                 raise TimeoutError("rank %d never voted" % q)
             time.sleep(0.01)
