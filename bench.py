@@ -485,11 +485,12 @@ def main():
     exchange = importlib.import_module("event-based-odomety_amd.exchange")
     comm_notes = {}
 
-    def make_comm(ctx_):
+    def make_comm(ctx_, probe=None):
         """The run's transport, chosen once the workload's context exists (the library's communicator lives on
-        a context).  `auto`: the library's own communicator, checked with one barrier + one reduction; every
-        rank votes (files, before any collective is relied on) and ALL ranks fall back to torch.distributed
-        together when one of them could not set it up."""
+        a context).  `auto`: the library's own communicator, checked with one barrier + one reduction and, when the
+        workload gives one, `probe(candidate)` = one whole untimed step on it (every collective the timed steps will
+        use, the grouped send / recv of the halo exchange among them); every rank votes (files, before any collective
+        is relied on) and ALL ranks fall back to torch.distributed together when one of them could not do that."""
         want_ebo = (world > 1 or force_dist) and not rehearse and args.comm in ("auto", "ebo")
         if want_ebo:
             cand, ok, why = EboComm(torch, ebo, exchange, rank, world), True, None
@@ -497,6 +498,8 @@ def main():
                 cand.attach(ctx_)
                 cand.barrier()
                 ok = cand.reduce(1.0, "SUM") == float(world)
+                if ok and probe is not None:
+                    probe(cand)
             except Exception as exc:
                 ok, why = False, repr(exc)
             if args.comm == "ebo":
@@ -505,7 +508,7 @@ def main():
                 return cand
             if exchange.agree(cand.prefix, rank, world, ok, timeout=900.0, not_before=T_START):
                 return cand
-            comm_notes["fallback"] = "the library's communicator could not be set up on every rank (%s): torch.distributed" % (why,)
+            comm_notes["fallback"] = "the library's communicator could not be set up and run one step on every rank (%s): torch.distributed" % (why,)
             try:
                 ctx_.comm_destroy()
             except Exception:
@@ -717,7 +720,6 @@ def main():
         wt = args.c4_windows if args.strong else args.c4_windows * world
         S = setup_c4(world, rank, wt)
         ctx, cfg = S["ctx"], S["cfg"]
-        comm = make_comm(ctx)
 
         def solve_only():
             ctx.solve_device(S["opts"], S["d_sol"].data_ptr(), S["d_stats"].data_ptr())
@@ -728,6 +730,13 @@ def main():
             if not args.no_c4_image:
                 c4_image(S)
 
+        def first_step_on(candidate):
+            nonlocal comm
+            comm = candidate
+            step()
+            torch.cuda.synchronize()
+
+        comm = make_comm(ctx, probe=first_step_on)
         step()
         torch.cuda.synchronize()
         if S["band"] is not None and int(S["B"]["flag"].item()) != 0:
@@ -746,7 +755,7 @@ def main():
                   "loss": "variance", "grad": "jet",
                   "event_evaluations": "events x the solver's evaluation requests (cost + Jacobian, from its statistics); a Jacobian "
                                        "request at the point whose cost was just evaluated runs the gather pass on the image that "
-                                       "evaluation left in LDS (bit-identical result; EBO_SOLVE_NO_REUSE=1 rebuilds the image)",
+                                       "evaluation left in LDS (bit-identical result; the A/B build's EBO_SOLVE_NO_REUSE=1 rebuilds the image)",
                   "step": "device-resident per-patch solve of the shard (ebo_solve_device) + one all-gather of the solved flows"
                           + ("" if args.no_c4_image else (
                               " + band-limited final image: the shard's events counted into its own rows + a halo (ebo_count_image_band), "
@@ -769,6 +778,10 @@ def main():
             else:
                 config["final_image"] = {"mode": "dense", "bytes_sent_per_rank_per_window": dense_bytes // 2 if world > 1 else 0,
                                          "dense_f64_image_bytes": dense_bytes}
+        if world > 1:
+            config["same_step_on_one_gpu"] = ("the N = 1 line's `value` is another workload (one batched evaluation of configs[2]); THIS step "
+                                              "on one GPU is that line's extras.c4_sharded_solve_step_1gpu.mevents_per_s (or `--gpus 1 --workload c4`), the "
+                                              "reference a scaling efficiency of this line has to be taken against")
         config.update(comm_notes)
 
     # ---- the timed region: W warm-up steps, barrier, EXACTLY K steps, barrier -----------------
