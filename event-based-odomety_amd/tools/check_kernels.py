@@ -16,7 +16,7 @@ translation unit that holds every kernel) and fails when a kernel
 
 Why: round 2's first k_solve_edge reached the edge objective from three sites of its solver loop; the
 compiler kept one out-of-line copy, passed the workgroup's LDS arrays as generic pointers, spilled 340
-VGPRs -- and the kernel faulted on the device.  tools/probe/solve_edge_outlined.hip
+VGPRs -- and the kernel faulted on the device (profiles/HISTORY_kernels.md).  tools/probe/solve_edge_outlined.hip
 rebuilds that shape; `check_kernels.py --expect-fail` on its assembly is part of the test-suite, so the
 gate is known to catch it.  Runs on the CPU box; nothing here touches a GPU.
 
