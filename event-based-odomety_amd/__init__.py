@@ -685,6 +685,17 @@ class Context:
             C.byref(opts) if opts is not None else None, _dp(poses), _dp(flow_dirs), sums))
         return poses, flow_dirs, list(sums)[:n]
 
+    def optimizer_cost_map(self, rects, nablas, poses, flow_dirs, map_w=11, map_h=11, normalize=False):
+        """Optimizer::drawCostMap for n patches: -> [n][map_h][map_w] (the L2 norm of the functor's residual image
+        at the map's translation offsets around each pose)."""
+        rects, nabla, poses, flow_dirs, sizes = self._opt_inputs(rects, nablas, poses, flow_dirs)
+        n = len(rects)
+        out = np.zeros((max(n, 1), map_h, map_w))
+        self._check(lib().ebo_optimizer_cost_map(
+            self._h, n, _dp(rects), _dp(nabla), int(bool(normalize)), _dp(poses), _dp(flow_dirs), int(map_w), int(map_h),
+            _dp(out)))
+        return out[:n]
+
     def estimate_num_events(self, rects, poses, flow_dirs):
         """FeatureDetector::updateNumOfEvents' event-count estimate for n tracked patches."""
         rects = np.ascontiguousarray(rects, dtype=np.float64).reshape(-1, 4)

@@ -417,6 +417,7 @@ struct OptLaunch
 };
 int launch_optimizer_eval(const OptLaunch& L, void* stream);
 int launch_optimizer_solve(const OptLaunch& L, void* stream);
+int launch_optimizer_cost_map(const OptLaunch& L, const double* d_xcells, int cells, double* d_out, void* stream);
 int launch_optimizer_normalize(const OptPatch* d_patches, int n, const double* d_in, double* d_out, void* stream);
 int launch_optimizer_interleave(const double* d_gx, const double* d_gy, size_t n, double2* d_grid, void* stream);
 int launch_estimate_num_events(const double2* d_grid, int w, int h, int n, const double* d_rects, const double* d_poses,

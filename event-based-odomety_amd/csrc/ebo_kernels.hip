@@ -3285,6 +3285,22 @@ int launch_optimizer_eval(const OptLaunch& L, void* stream)
 	return check_launch();
 }
 
+int launch_optimizer_cost_map(const OptLaunch& L, const double* d_xcells, int cells, double* d_out, void* stream)
+{
+	if (L.n_patches == 0 || cells == 0)
+	{
+		return 0;
+	}
+	const size_t lds = optimizer_lds_bytes(L.max_pixels);
+	if (lds > 160 * 1024 - 512 || allow_big_lds(k_optimizer_cost_map, lds))
+	{
+		return -2;
+	}
+	hipLaunchKernelGGL(k_optimizer_cost_map, dim3(cells, L.n_patches), dim3(256), lds, static_cast<hipStream_t>(stream),
+					   L.d_grid, L.img_w, L.img_h, L.d_patches, L.d_nabla, d_xcells, d_out);
+	return check_launch();
+}
+
 int launch_optimizer_solve(const OptLaunch& L, void* stream)
 {
 	if (L.n_patches == 0)

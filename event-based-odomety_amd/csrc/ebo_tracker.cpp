@@ -706,6 +706,92 @@ int ebo_optimizer_eval(ebo_ctx* c, int n, const double* rects, const double* nab
 	return c->hip(e, "D2H optimizer results");
 }
 
+int ebo_optimizer_cost_map(ebo_ctx* c, int n, const double* rects, const double* nabla, int normalize, const double* poses,
+						   const double* flow_dirs, int map_w, int map_h, double* cost_maps)
+{
+	if (!c)
+	{
+		return EBO_ERR_ARG;
+	}
+	if (c->capturing)
+	{
+		return c->fail(EBO_ERR_STATE, kNotWhileRecording);
+	}
+	if (map_w < 1 || map_h < 1 || map_w > 255 || map_h > 255 || (n > 0 && !cost_maps))
+	{
+		return c->fail(EBO_ERR_ARG, "cost map: 1 <= width, height <= 255 and an output buffer");
+	}
+	OptBuffers B;
+	int rc = optimizer_stage(c, n, rects, nabla, normalize, poses, flow_dirs, false, false, B);
+	if (rc || n == 0)
+	{
+		return rc;
+	}
+	// poseNew of optimizer.cpp:46-51, on the host as the reference forms it: SE2(pose.log().z(), (float(x) + tx, float(y) + ty))
+	// -- the angle through atan2 and back through cos / sin -- for x (outer) and y (inner); cell (y + hy, x + hx) of the map
+	const int cells = map_w * map_h, hx = (map_w - 1) / 2, hy = (map_h - 1) / 2;
+	std::vector<double> hxc(static_cast<size_t>(n) * cells * 5, 0.0);
+	std::vector<uint8_t> filled(static_cast<size_t>(cells), 0);
+	for (int i = 0; i < n; ++i)
+	{
+		const double* ps = poses + 4 * static_cast<size_t>(i);
+		const double theta = std::atan2(ps[1], ps[0]);
+		const double ct = std::cos(theta), st = std::sin(theta);
+		for (int x = -hx; x <= hx; ++x)
+		{
+			for (int y = -hy; y <= hy; ++y)
+			{
+				double* o = &hxc[(static_cast<size_t>(i) * cells + static_cast<size_t>(y + hy) * map_w + (x + hx)) * 5];
+				o[0] = ct;
+				o[1] = st;
+				o[2] = static_cast<double>(static_cast<float>(x)) + ps[2];
+				o[3] = static_cast<double>(static_cast<float>(y)) + ps[3];
+				o[4] = flow_dirs[i];
+				filled[static_cast<size_t>(y + hy) * map_w + (x + hx)] = 1;
+			}
+		}
+	}
+	const size_t bx = hxc.size() * 8, bo = static_cast<size_t>(n) * cells * 8;
+	rc = ensure_scratch(c, bx + bo + 256);
+	if (rc)
+	{
+		return rc;
+	}
+	double* dX = static_cast<double*>(c->d_scratch);
+	double* dOut = reinterpret_cast<double*>(static_cast<char*>(c->d_scratch) + ((bx + 255) & ~static_cast<size_t>(255)));
+	hipError_t e = hipMemcpyAsync(dX, hxc.data(), bx, hipMemcpyHostToDevice, c->stream);
+	if (e != hipSuccess)
+	{
+		(void)hipStreamSynchronize(c->stream);
+		return c->hip(e, "H2D cost-map poses");
+	}
+	OptLaunch L = optimizer_launch(c, n, B);
+	if (launch_optimizer_cost_map(L, dX, cells, dOut, c->stream))
+	{
+		(void)hipStreamSynchronize(c->stream);
+		return c->hip(hipGetLastError(), "cost-map launch");
+	}
+	e = hipMemcpyAsync(cost_maps, dOut, bo, hipMemcpyDeviceToHost, c->stream);
+	const hipError_t es = hipStreamSynchronize(c->stream);
+	rc = c->hip(e != hipSuccess ? e : es, "D2H cost maps");
+	if (rc)
+	{
+		return rc;
+	}
+	// an even width / height leaves the last column / row of cv::Mat::zeros untouched (:43-45 visit 2 * half + 1 cells)
+	for (int i = 0; i < n; ++i)
+	{
+		for (int q = 0; q < cells; ++q)
+		{
+			if (!filled[q])
+			{
+				cost_maps[static_cast<size_t>(i) * cells + q] = 0.0;
+			}
+		}
+	}
+	return EBO_OK;
+}
+
 int ebo_optimizer_solve(ebo_ctx* c, int n, const double* rects, const double* nabla, int normalize, double huber,
 						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries)
 {

@@ -12,8 +12,8 @@
 // ebo_patch_integrate, ebo_optimizer_solve (normalisation of the integrated nabla included),
 // ebo_patch_integrate_mc.  Nothing but the per-patch bookkeeping runs on the CPU.
 //
-// Not built: drawCostMap (OptimizerParams::drawCostMap, off by default in the reference, "it is
-// too slow" there): requesting it throws.
+// OptimizerParams::drawCostMap (optimizer.cpp:33-60, off by default, "it is too slow" there): the cost
+// maps of all surviving patches in one more launch (ebo_optimizer_cost_map), into Patch::setCostMap.
 #pragma once
 
 #include <algorithm>
@@ -95,10 +95,6 @@ class Optimizer
 
 	void optimize(const std::vector<Patch*>& patches)
 	{
-		if (params_.drawCostMap)
-		{
-			throw std::runtime_error("tracker::Optimizer: drawCostMap is not built");
-		}
 		const int n = static_cast<int>(patches.size());
 		if (n == 0)
 		{
@@ -252,6 +248,30 @@ class Optimizer
 		for (int i : alive)
 		{
 			patches[i]->resetBatch();
+		}
+		// ---- drawCostMap (optimizer.cpp:33-60,191-204), all surviving patches in one launch: the functor of the
+		// optimisation -- the rect and the integrated nabla from BEFORE the solve -- at the solved pose and flow
+		if (params_.drawCostMap && !alive.empty())
+		{
+			const int k = static_cast<int>(alive.size()), mw = params_.costMapWidth, mh = params_.costMapHeight;
+			std::vector<double> rects3(4 * static_cast<size_t>(k)), poses3(4 * static_cast<size_t>(k)), flows3(k), nabla3;
+			for (int j = 0; j < k; ++j)
+			{
+				const int i = alive[j];
+				std::copy(rects.begin() + 4 * i, rects.begin() + 4 * i + 4, rects3.begin() + 4 * j);
+				std::copy(patches[i]->getWarp().data(), patches[i]->getWarp().data() + 4, poses3.begin() + 4 * j);
+				flows3[j] = patches[i]->getFlow();  // double flowDir = patch.getFlow(): through float (:37)
+				const size_t m = static_cast<size_t>(static_cast<int>(rects[4 * i + 3])) * static_cast<int>(rects[4 * i + 2]);
+				nabla3.insert(nabla3.end(), nabla.begin() + nablaOff[i], nabla.begin() + nablaOff[i] + m);
+			}
+			std::vector<double> maps(static_cast<size_t>(k) * mw * mh, 0.0);
+			check(ebo_optimizer_cost_map(ctx_, k, rects3.data(), nabla3.data(), 1, poses3.data(), flows3.data(), mw, mh, maps.data()));
+			for (int j = 0; j < k; ++j)
+			{
+				Mat64 m(mh, mw);
+				std::copy(maps.begin() + static_cast<size_t>(j) * mw * mh, maps.begin() + static_cast<size_t>(j + 1) * mw * mh, m.ptr());
+				patches[alive[j]]->setCostMap(m);
+			}
 		}
 	}
 

@@ -340,6 +340,16 @@ int ebo_optimizer_eval(ebo_ctx* ctx, int n, const double* rects, const double* n
 int ebo_optimizer_solve(ebo_ctx* ctx, int n, const double* rects, const double* nabla, int normalize, double huber,
 						const ebo_solver_opts* opts, double* poses, double* flow_dirs, ebo_summary* summaries);
 
+/* tracker::Optimizer::drawCostMap (optimizer.cpp:33-60; OptimizerParams::drawCostMap, costMapWidth / costMapHeight) for n
+ * tracked patches in one launch: cost_maps [n][map_h][map_w], cell (y + (map_h-1)/2, x + (map_w-1)/2) = cv::norm(image, NORM_L2)
+ * of the functor's residual image (its double path, as `(*c)(poseNew.data(), &flowDir, image.data)` evaluates it) at
+ * poseNew = SE2(pose.log().z(), (float(x) + tx, float(y) + ty)), x = -(map_w-1)/2 .. (map_w-1)/2, y likewise (cells an even
+ * size leaves unvisited stay 0, as in cv::Mat::zeros).  rects / nabla / normalize / poses / flow_dirs as for
+ * ebo_optimizer_solve; the reference calls it after the solve with the functor built BEFORE it (the rect and the
+ * normalised nabla of the optimisation) and the solved pose and flow.  EBO_ERR_STATE without ebo_optimizer_set_grad. */
+int ebo_optimizer_cost_map(ebo_ctx* ctx, int n, const double* rects, const double* nabla, int normalize, const double* poses,
+						   const double* flow_dirs, int map_w, int map_h, double* cost_maps);
+
 /* The event-count estimate of FeatureDetector::updateNumOfEvents (feature_detector.cpp:689-707) for n
  * tracked patches in one launch: the L1 norm over the patch rect of
  * 0.6 gradX' cos(flow) + 0.6 gradY' sin(flow), gradX' / gradY' = the gradient images of

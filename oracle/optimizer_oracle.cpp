@@ -880,6 +880,44 @@ int orc_optimizer_cost(const double* grad, int img_w, int img_h, double rx, doub
 	return 0;
 }
 
+// Optimizer::drawCostMap (optimizer.cpp:33-60): costMap(y + (H-1)/2, x + (W-1)/2) = cv::norm(image, NORM_L2) of the
+// functor's residual image at poseNew = SE2(pose.log().z(), (float(x) + tx, float(y) + ty)); pose.log().z() is
+// Sophus' SO2::log = atan2(sin, cos), and SE2(theta, t) stores (cos theta, sin theta).  flow_dir: the caller passes
+// patch.getFlow(), i.e. the double member rounded through float (patch.h:56).  out [map_h][map_w], zeros first
+// (cv::Mat::zeros: an even size leaves its last row / column unvisited).
+int orc_optimizer_cost_map(const double* grad, int img_w, int img_h, double rx, double ry, double rw, double rh,
+						   const double* nabla, const double* pose, double flow_dir, int map_w, int map_h, double* out)
+{
+	Functor fn;
+	if (!pose || !out || map_w < 1 || map_h < 1 || !makeFunctor(grad, img_w, img_h, rx, ry, rw, rh, nabla, fn))
+	{
+		return -1;
+	}
+	const int n = fn.pw * fn.ph;
+	std::vector<double> image(static_cast<size_t>(n));
+	for (int i = 0; i < map_w * map_h; ++i)
+	{
+		out[i] = 0.0;
+	}
+	const double theta = std::atan2(pose[1], pose[0]);
+	for (int x = -(map_w - 1) / 2; x <= (map_w - 1) / 2; ++x)
+	{
+		for (int y = -(map_h - 1) / 2; y <= (map_h - 1) / 2; ++y)
+		{
+			const double poseNew[4] = {std::cos(theta), std::sin(theta), static_cast<float>(x) + pose[2],
+									   static_cast<float>(y) + pose[3]};
+			evaluateFunctor(fn, poseNew, flow_dir, image.data(), nullptr, nullptr);
+			double ss = 0.0;
+			for (int i = 0; i < n; ++i)
+			{
+				ss += image[i] * image[i];
+			}
+			out[(y + (map_h - 1) / 2) * map_w + (x + (map_w - 1) / 2)] = std::sqrt(ss);
+		}
+	}
+	return 0;
+}
+
 void orc_optimizer_default_solver(orc_solver_opts* o)
 {
 	orc_default_solver(o);

@@ -368,6 +368,20 @@ def optimizer_cost(grad, rect, nabla, pose, flow_dir, want_jac=True):
     return res, jp, jf
 
 
+def optimizer_cost_map(grad, rect, nabla, pose, flow_dir, map_w=11, map_h=11):
+    """Optimizer::drawCostMap (optimizer.cpp:33-60) -> [map_h][map_w]."""
+    grad = np.ascontiguousarray(grad, dtype=np.float64)
+    nabla = np.ascontiguousarray(nabla, dtype=np.float64)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    h, w = grad.shape[:2]
+    out = np.zeros((map_h, map_w))
+    rc = lib().orc_optimizer_cost_map(
+        _dp(grad), w, h, C.c_double(rect[0]), C.c_double(rect[1]), C.c_double(rect[2]), C.c_double(rect[3]),
+        _dp(nabla), _dp(pose), C.c_double(flow_dir), int(map_w), int(map_h), _dp(out))
+    assert rc == 0
+    return out
+
+
 def optimizer_default_solver(**kw):
     o = SolverOpts()
     lib().orc_optimizer_default_solver(C.byref(o))

@@ -134,3 +134,28 @@ def test_front_end_lines_with_opencv_types_run_like_the_pair(ebo):
     print(out.stdout[-4000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-4000:]
     assert "all passed" in out.stdout
+
+
+def test_patch_lines_compile_and_host_subset(ebo):
+    """CPU: the reference's own patch tests (patch_test.cpp:7-33,35-60 verbatim; :62-91 with its OpenCV / Sophus
+    statements restated) compile under -Wall -Wextra against the facade's tracker::Patch; the host-only subset runs:
+    addEventsTest ends as the reference's patch.cpp implies (three of its expectations are stale there), the
+    bookkeeping getters, and every per-patch device member throws "no device context" when none is bound."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "patch_lines_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+    run = subprocess.run([os.path.join(CPP, "patch_lines_test"), "--cpu"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and ": OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_patch_lines_run_on_the_device(ebo):
+    """integrateEventsTest and warpImageTest of the reference through the per-patch members (one launch each),
+    integrateMotionCompensatedEvents against patch.cpp:87-130 written out in the test, warpImage() away from the
+    border = the batched ABI call, OptimizerParams::drawCostMap through Optimizer::optimize = ebo_optimizer_cost_map."""
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "patch_lines_test"])
+    out = subprocess.run([os.path.join(CPP, "patch_lines_test")], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-4000:], out.stderr[-2000:])
+    assert out.returncode == 0 and ": OK" in out.stdout, out.stdout[-4000:]

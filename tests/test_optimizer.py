@@ -244,6 +244,59 @@ def test_device_functor_matches_oracle(ebo, orc):
         assert np.abs(jf[i] - jfo).max() <= 1e-11 * max(np.abs(jfo).max(), 1e-300) + 1e-15
 
 
+def test_cost_map_restatement_against_single_evaluations(orc):
+    """Optimizer::drawCostMap (optimizer.cpp:33-60) on the oracle: every cell is the L2 norm of ONE functor evaluation
+    at the shifted pose (independent numpy restatement of the loop), the centre cell is the norm at the pose itself, an
+    even map size leaves its last row / column zero."""
+    grad, items = _batch(orc, 2)
+    it = items[0]
+    pose = pose_of(0.03, 0.6, -0.4)
+    flow = float(np.float32(1.1))
+    cm = orc.optimizer_cost_map(grad, it["rect"], it["nabla"], pose, flow, 5, 7)
+    theta = np.arctan2(pose[1], pose[0])
+    for x in range(-2, 3):
+        for y in range(-3, 4):
+            p2 = np.array([np.cos(theta), np.sin(theta), np.float32(x) + pose[2], np.float32(y) + pose[3]])
+            r, _, _ = orc.optimizer_cost(grad, it["rect"], it["nabla"], p2, flow, want_jac=False)
+            assert abs(cm[y + 3, x + 2] - np.sqrt((r * r).sum())) <= 1e-13 * cm[y + 3, x + 2]
+    even = orc.optimizer_cost_map(grad, it["rect"], it["nabla"], pose, flow, 4, 6)
+    assert np.all(even[:, 3] == 0.0) and np.all(even[5, :] == 0.0) and np.all(even[:5, :3] > 0.0)
+
+
+@pytest.mark.gpu
+def test_device_cost_map_matches_oracle(ebo, orc):
+    """ebo_optimizer_cost_map against the oracle's drawCostMap: 11 x 11 (the reference's default), a non-square and an
+    even-sized map, raw nabla normalised on the device and pre-normalised nabla, patches at the border and outside."""
+    grad, items = _batch(orc, 7)
+    items[1]["rect"] = (228.0, 170.0, 25.0, 25.0)            # hangs over the image border
+    items[2]["start"] = (pose_of(0.0, 600.0, 0.0), 1.0)      # completely outside after the warp
+    rects = [it["rect"] for it in items]
+    poses = [pose_of(it["true"][0] + 0.01, *it["true"][1]) for it in items]
+    poses[2] = items[2]["start"][0]
+    fds = [float(np.float32(it["true"][2])) for it in items]
+    c = _ctx(ebo)
+    try:
+        with pytest.raises(ebo.EboError):
+            c.optimizer_cost_map(rects, [it["nabla"] for it in items], poses, fds)
+        c.optimizer_set_grad(grad[..., 0], grad[..., 1])
+        maps = {}
+        for mw, mh in ((11, 11), (5, 7), (4, 6)):
+            maps[(mw, mh)] = c.optimizer_cost_map(rects, [it["nabla"] for it in items], poses, fds, mw, mh)
+        raw = c.optimizer_cost_map(rects, [it["raw"] for it in items], poses, fds, 11, 11, normalize=True)
+        with pytest.raises(ebo.EboError):
+            c.optimizer_cost_map(rects, [it["nabla"] for it in items], poses, fds, 0, 11)
+    finally:
+        c.close()
+    for (mw, mh), got in maps.items():
+        for i, it in enumerate(items):
+            want = orc.optimizer_cost_map(grad, it["rect"], it["nabla"], poses[i], fds[i], mw, mh)
+            assert np.abs(got[i] - want).max() <= 1e-12 * want.max(), (mw, mh, i)
+            assert np.array_equal(got[i] == 0.0, want == 0.0)
+    for i, it in enumerate(items):
+        want = orc.optimizer_cost_map(grad, it["rect"], orc.normalize_nabla(it["raw"]), poses[i], fds[i], 11, 11)
+        assert np.abs(raw[i] - want).max() <= 1e-12 * want.max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("iters", [1, 3, 10, 40])
 def test_device_solve_matches_oracle(ebo, orc, iters):
