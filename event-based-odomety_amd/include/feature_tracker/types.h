@@ -25,6 +25,7 @@ class Mat64 : public cv::Mat
    public:
 	Mat64() = default;
 	Mat64(int r, int c) : cv::Mat(cv::Mat::zeros(r, c, CV_64F)) {}
+	Mat64(const cv::Mat& m) : cv::Mat(m) {}  // a CV_64F image of the caller's (cv::Mat copies are shallow)
 	double* ptr() { return cv::Mat::ptr<double>(0); }
 	const double* ptr() const { return cv::Mat::ptr<double>(0); }
 };

@@ -188,7 +188,14 @@ inline Jet<T, N> abs(const Jet<T, N>& f)  // jet.h: abs(a + h) ~= abs(a) + sgn(a
 }
 inline double abs(double x) { return std::abs(x); }
 
-// ceres/autodiff_cost_function.h (static sizes only).  Evaluate without Jacobians calls the functor
+// ceres/types.h: the residual count of a cost function whose size is given at run time
+enum
+{
+	DYNAMIC = -1
+};
+
+// ceres/autodiff_cost_function.h (static parameter-block sizes; kNumResiduals static or DYNAMIC with the count given to
+// the constructor, as `AutoDiffCostFunction<F, ceres::DYNAMIC, 4, 1>(functor, size)` of optimizer.cpp:91-97).  Evaluate without Jacobians calls the functor
 // on doubles; with Jacobians it evaluates the functor once on Jet<double, N0 + N1 + ...>, parameter
 // j of block i seeded with the unit partial offset_i + j, and copies output[k].v[offset_i + j] into
 // jacobians[i][k * Ni + j] for every block whose Jacobian was asked for.
@@ -203,6 +210,13 @@ class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...>
 	explicit AutoDiffCostFunction(CostFunctor* functor, Ownership ownership = TAKE_OWNERSHIP)
 		: functor_(functor), ownership_(ownership)
 	{
+		static_assert(kNumResiduals != DYNAMIC, "a DYNAMIC cost function takes its residual count in the constructor");
+	}
+	AutoDiffCostFunction(CostFunctor* functor, int num_residuals, Ownership ownership = TAKE_OWNERSHIP)
+		: functor_(functor), ownership_(ownership)
+	{
+		static_assert(kNumResiduals == DYNAMIC, "only a DYNAMIC cost function takes a residual count");
+		this->set_num_residuals(num_residuals);
 	}
 	~AutoDiffCostFunction() override
 	{
@@ -230,12 +244,14 @@ class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...>
 			}
 			offset += sizes[i];
 		}
-		JetT out[kNumResiduals];
+		const int nres = this->num_residuals();
+		std::vector<JetT> outv(static_cast<size_t>(nres));
+		JetT* out = outv.data();
 		if (!call(blocks, out, std::make_index_sequence<kNumBlocks>()))
 		{
 			return false;
 		}
-		for (int k = 0; k < kNumResiduals; ++k)
+		for (int k = 0; k < nres; ++k)
 		{
 			residuals[k] = out[k].a;
 		}
@@ -244,7 +260,7 @@ class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...>
 		{
 			if (jacobians[i] != nullptr)
 			{
-				for (int k = 0; k < kNumResiduals; ++k)
+				for (int k = 0; k < nres; ++k)
 				{
 					for (int j = 0; j < sizes[i]; ++j)
 					{

@@ -159,3 +159,28 @@ def test_patch_lines_run_on_the_device(ebo):
     out = subprocess.run([os.path.join(CPP, "patch_lines_test")], capture_output=True, text=True, timeout=600)
     print(out.stdout[-4000:], out.stderr[-2000:])
     assert out.returncode == 0 and ": OK" in out.stdout, out.stdout[-4000:]
+
+
+def test_optimizer_cost_lines_compile_and_host_subset(ebo):
+    """CPU: the reference's statements that build the tracker's Ceres cost function (optimizer.cpp:9,15-31,72-79,86-97:
+    the interleaved grid, `new Grid`, `new Interpolator`, `new tracker::OptimizerCostFunctor`, `new
+    ceres::AutoDiffCostFunction<tracker::OptimizerCostFunctor, ceres::DYNAMIC, Sophus::SE2d::num_parameters, 1>`) compile
+    verbatim under -Wall -Wextra against <feature_tracker/optimizer_cost.h> (test-only Ceres / OpenCV declarations); a
+    functor without an interpolator reports failure."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "optimizer_cost_lines_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+    run = subprocess.run([os.path.join(CPP, "optimizer_cost_lines_test"), "--cpu"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and ": OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_optimizer_cost_lines_evaluate_like_the_abi(ebo):
+    """AutoDiffCostFunction<OptimizerCostFunctor, DYNAMIC, 4, 1>::Evaluate through the facade functor (Jet path, one
+    launch) = ebo_optimizer_eval on another context, bit for bit: residuals, both Jacobian blocks, one block, none."""
+    ebo.lib()
+    subprocess.check_call(["make", "-s", "-C", CPP, "optimizer_cost_lines_test"])
+    out = subprocess.run([os.path.join(CPP, "optimizer_cost_lines_test")], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-4000:], out.stderr[-2000:])
+    assert out.returncode == 0 and ": OK" in out.stdout, out.stdout[-4000:]
