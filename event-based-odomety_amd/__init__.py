@@ -309,6 +309,18 @@ def read_events_txt(path, cap=1 << 22):
     return out[: n.value].copy()
 
 
+def read_events_txt_at(path, offset, cap=1_000_000):
+    """At most cap events of an events.txt from byte `offset` on -> (events, next offset): the pieces
+    Davis240cReader::getEvents reads a recording in (EVENT_LENGTH lines per call)."""
+    out = np.zeros(cap, dtype=EVENT_DTYPE)
+    n = C.c_size_t()
+    off = C.c_uint64(int(offset))
+    rc = lib().ebo_read_events_txt_at(str(path).encode(), C.byref(off), _vp(out), C.c_size_t(cap), C.byref(n))
+    if rc:
+        raise EboError(rc, "cannot parse %s (parsed %d events before the error)" % (path, n.value))
+    return out[: n.value].copy(), int(off.value)
+
+
 def write_events_bin(path, ev):
     """Packed binary sidecar (32-byte header + 16 B per event) of an event array."""
     ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)

@@ -137,7 +137,10 @@ int ebo_read_events_bin(const char* path, ebo_event* out, size_t cap, size_t* n)
 // DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one
 // event per line "<seconds> <x> <y> <0|1>".  Seconds go through a double and are
 // truncated to microseconds, exactly as std::stod + duration_cast do there.
-int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
+namespace
+{
+// at most cap events from byte *offset on (null: from the start); *offset moves behind the last line taken
+int read_events_txt(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n)
 {
 	if (!path || !n || (cap && !out))
 	{
@@ -149,10 +152,17 @@ int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
 	{
 		return EBO_ERR_ARG;
 	}
+	uint64_t pos = offset ? *offset : 0;  // first byte not yet consumed
+	if (pos && fseeko(fp, static_cast<off_t>(pos), SEEK_SET) != 0)
+	{
+		std::fclose(fp);
+		return EBO_ERR_ARG;
+	}
 	std::vector<char> buf(1 << 20);
 	std::string line;
 	size_t count = 0;
 	int rc = EBO_OK;
+	// true: the line is consumed (an event, or blank); false: stop in front of it
 	auto take = [&](const std::string& ln) -> bool {
 		const char* s = ln.c_str();
 		char* end = nullptr;
@@ -209,6 +219,10 @@ int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
 			{
 				line.append(buf.data() + start, i - start);
 				go = take(line);
+				if (go)
+				{
+					pos += line.size() + 1;
+				}
 				line.clear();
 				start = i + 1;
 			}
@@ -218,13 +232,32 @@ int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
 			line.append(buf.data() + start, got - start);
 		}
 	}
-	if (go && !line.empty())
+	if (go && !line.empty() && take(line))
 	{
-		take(line);
+		pos += line.size();  // a last line without a newline
 	}
 	std::fclose(fp);
 	*n = count;
+	if (offset)
+	{
+		*offset = pos;
+	}
 	return rc;
+}
+}  // namespace
+
+int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
+{
+	return read_events_txt(path, nullptr, out, cap, n);
+}
+
+int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n)
+{
+	if (!offset)
+	{
+		return EBO_ERR_ARG;
+	}
+	return read_events_txt(path, offset, out, cap, n);
 }
 
 // trajectory.txt of tools::Evaluator::saveFeaturesTrajectory (tools/evaluator/src/evaluator.cpp:125-150):

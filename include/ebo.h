@@ -490,6 +490,10 @@ int ebo_patch_integrate_mc(ebo_ctx* ctx, const ebo_event* ev, const size_t* offs
  * line -> out[0..*n), at most cap events.  Host only; EBO_ERR_RANGE on a malformed line or a
  * sign other than 0/1 (the reference throws there), events parsed before it are kept. */
 int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n);
+/* The same in pieces, as Davis240cReader::getEvents reads a recording (davis240c_reader.cpp:186-212: EVENT_LENGTH =
+ * 1 000 000 lines per call, the next call continues behind them): at most cap events from byte *offset of the file on;
+ * *offset moves behind the last line taken (start with 0; *n == 0 with EBO_OK = the end of the file). */
+int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n);
 
 /* Contiguous shard [begin,end) of n_units for rank of world (multi-GPU, §8e). */
 int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end);

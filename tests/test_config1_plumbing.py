@@ -53,6 +53,35 @@ def test_events_txt_round_trip_and_reader_fixture(ebo, orc, stream_file):
     assert fx["t_us"].tolist() == [0, 11, 50, 55, 80]
 
 
+def test_events_txt_in_pieces(ebo, stream_file, tmp_path):
+    """ebo_read_events_txt_at: a recording read in pieces of any size (Davis240cReader::getEvents reads 1 000 000 lines
+    per call and continues behind them) gives the whole-file parse; the offset ends at the file's size; a piece that stops
+    in front of a bad line keeps what it parsed and reports EBO_ERR_RANGE; a last line without a newline is taken."""
+    path, _ = stream_file
+    whole = ebo.read_events_txt(path)
+    for cap in (1, 7, 1000, len(whole), len(whole) + 5):
+        off, parts = 0, []
+        for _ in range(len(whole) // cap + 3):
+            ev, off = ebo.read_events_txt_at(path, off, cap)
+            if len(ev) == 0:
+                break
+            assert len(ev) <= cap
+            parts.append(ev)
+        assert np.array_equal(np.concatenate(parts), whole), cap
+        assert off == os.path.getsize(path)
+        if cap >= 1000:
+            break_after = len(parts)
+            assert break_after == -(-len(whole) // cap)
+    p = tmp_path / "tail.txt"
+    p.write_text("0.000001 1 2 1\n0.000002 3 4 0")  # no newline at the end
+    ev, off = ebo.read_events_txt_at(str(p), 0, 10)
+    assert ev["x"].tolist() == [1, 3] and off == os.path.getsize(p)
+    q = tmp_path / "bad.txt"
+    q.write_text("0.000001 1 2 1\n0.000002 3 4 5\n")
+    with pytest.raises(ebo.EboError):
+        ebo.read_events_txt_at(str(q), 0, 10)
+
+
 def test_binary_sidecar_round_trip(ebo, stream_file, tmp_path):
     """The packed sidecar gives back exactly what the text reader parsed (SURVEY §8(f) #3)."""
     import time

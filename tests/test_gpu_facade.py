@@ -184,3 +184,17 @@ def test_optimizer_cost_lines_evaluate_like_the_abi(ebo):
     out = subprocess.run([os.path.join(CPP, "optimizer_cost_lines_test")], capture_output=True, text=True, timeout=600)
     print(out.stdout[-4000:], out.stderr[-2000:])
     assert out.returncode == 0 and ": OK" in out.stdout, out.stdout[-4000:]
+
+
+def test_reference_reader_lines(ebo, tmp_path):
+    """CPU: tools/dataset_reader/test/davis240c_reader_test.cpp:19-48 (eventsTest) verbatim against the facade's
+    tools::Davis240cReader on the reference's own events.txt fixture; a 2.3 M-event recording read in the reference's
+    pieces of EVENT_LENGTH lines (ebo_read_events_txt_at) and again from the packed sidecar; the reference's exception text
+    for a bad sign; trajectory.txt read back one Patch per line."""
+    ebo.lib()
+    out = subprocess.run(["make", "-B", "-C", CPP, "reader_lines_test"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "warning" not in out.stderr, out.stderr[-3000:]
+    run = subprocess.run([os.path.join(CPP, "reader_lines_test"), os.path.join(HERE, "golden", "davis_events_fixture.txt"), str(tmp_path)],
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and ": OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
