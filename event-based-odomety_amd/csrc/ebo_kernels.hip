@@ -124,6 +124,21 @@ __device__ __forceinline__ T wave_reduce(T v, T idle, Op op)
 	return v;
 }
 
+// One 8-byte LDS read that stays ONE ds_read_b64.  The compiler pairs neighbouring 8-byte reads of one base into
+// ds_read2_b64, which the LDS serves as two accesses in four groups of 16 lanes (128 B/clk/CU, banks mod 32) where a
+// ds_read_b64 goes in two groups of 32 lanes (256 B/clk/CU, banks mod 64): with per-lane random bases -- every lane
+// reads at its own event's footprint -- the paired form is the slower one.  A relaxed wavefront-scope atomic load is
+// the same instruction, and the load / store optimiser leaves ordered accesses alone.
+__device__ __forceinline__ double lds_ld(const double* p)
+{
+#ifdef EBO_LDS_PAIRED_READS
+	return *p;
+#else
+	return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+														__HIP_MEMORY_SCOPE_WAVEFRONT));
+#endif
+}
+
 __device__ __forceinline__ double wave_sum(double v)  // total in lane kWaveResultLane
 {
 	return wave_reduce(v, 0.0, [](double a, double b) { return a + b; });
