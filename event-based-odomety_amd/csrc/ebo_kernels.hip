@@ -124,6 +124,18 @@ __device__ __forceinline__ T wave_reduce(T v, T idle, Op op)
 	return v;
 }
 
+// The fixed-point form of a tap is the double (value + bias) with the bias's high dword taken off its high dword: ONE
+// 32-bit subtract, the low dword goes as it is.  Left alone, the compiler re-forms the 64-bit difference (the double as
+// an integer minus biasHi << 32) and spends v_subrev_co_u32 (low dword minus 0, for a carry that is always 0) + s_nop +
+// v_subb_co_u32 per tap -- 49 times per event in the scatter, 64 times per entry in the edge loss's reverse pass.  An
+// empty asm on the high dword keeps the halves apart.
+__device__ __forceinline__ void keep32(unsigned int& v)
+{
+#ifndef EBO_FIX_UNPINNED
+	asm volatile("" : "+v"(v));
+#endif
+}
+
 // One 8-byte LDS read that stays ONE ds_read_b64.  The compiler pairs neighbouring 8-byte reads of one base into
 // ds_read2_b64, which the LDS serves as two accesses in four groups of 16 lanes (128 B/clk/CU, banks mod 32) where a
 // ds_read_b64 goes in two groups of 32 lanes (256 B/clk/CU, banks mod 64): with per-lane random bases -- every lane
