@@ -40,10 +40,19 @@ __global__ void k_atomic(T* out, int iters)
 			h = h * 1664525u + 1013904223u;
 			a = ((h >> 10) + (threadIdx.x & 63) % 7 + (it % 7) * 41) & (LDS_ELEMS - 1);
 		}
-		else
+		else if (PATTERN == 6)
 		{
 			if (it % 49 == 0) { rnd = rnd * 1664525u + 1013904223u; }
 			a = ((rnd >> 10) + (it % 7) + ((it / 7) % 7) * 41) & (LDS_ELEMS - 1);
+		}
+		else
+		{
+			// 7 / 8: as 6, but the random bases of the lanes of one group of 16 (7) or 32 (8) lanes are pairwise distinct
+			// modulo the group's size: what an ideal dealing of events over lanes would reach
+			constexpr unsigned G = PATTERN == 7 ? 16u : 32u;
+			if (it % 49 == 0) { rnd = rnd * 1664525u + 1013904223u; }
+			const unsigned base = (((rnd >> 10) & ~(G - 1u)) | (threadIdx.x & (G - 1u)));
+			a = (base + (it % 7) + ((it / 7) % 7) * 41) & (LDS_ELEMS - 1);
 		}
 		atomicAdd(&lds[a], v);
 	}
@@ -74,10 +83,17 @@ __global__ void k_read(double* out, int iters)
 			h = h * 1664525u + 1013904223u;
 			a = ((h >> 10) + (threadIdx.x & 63) % 7 + (it % 7) * 41) & (LDS_ELEMS - 1);
 		}
-		else
+		else if (PATTERN == 6)
 		{
 			if (it % 49 == 0) { rnd = rnd * 1664525u + 1013904223u; }
 			a = ((rnd >> 10) + (it % 7) + ((it / 7) % 7) * 41) & (LDS_ELEMS - 1);
+		}
+		else
+		{
+			constexpr unsigned G = PATTERN == 7 ? 16u : 32u;
+			if (it % 49 == 0) { rnd = rnd * 1664525u + 1013904223u; }
+			const unsigned base = (((rnd >> 10) & ~(G - 1u)) | (threadIdx.x & (G - 1u)));
+			a = (base + (it % 7) + ((it / 7) % 7) * 41) & (LDS_ELEMS - 1);
 		}
 		acc += lds[a];
 	}
@@ -156,6 +172,11 @@ int main(int argc, char** argv)
 		run("ds_read_b64 random", k_read<1>, blocks, threads, nullptr);
 		run("ds_read_b64 7-lane groups", k_read<5>, blocks, threads, nullptr);
 		run("ds_read_b64 random base + tap", k_read<6>, blocks, threads, nullptr);
+		// what an ideal dealing of a wave's events over its lanes would reach: bases distinct mod 16 (32) in a lane group
+		run("ds_add_u64 base+tap, distinct mod 16", k_atomic<unsigned long long, 7>, blocks, threads, nullptr);
+		run("ds_add_u64 base+tap, distinct mod 32", k_atomic<unsigned long long, 8>, blocks, threads, nullptr);
+		run("ds_read_b64 base+tap, distinct mod 16", k_read<7>, blocks, threads, nullptr);
+		run("ds_read_b64 base+tap, distinct mod 32", k_read<8>, blocks, threads, nullptr);
 	}
 	return 0;
 }
