@@ -62,6 +62,47 @@ __global__ void k_atomic(T* out, int iters)
 	if (s == T(12345)) out[blockIdx.x] = s;
 }
 
+// The kernels' own shape: per "event" a random base per lane, then 7 x 7 taps at IMMEDIATE offsets (row pitch 41 slots).
+// MODE 0: any base; 1 / 2: the bases of the lanes of a group of 16 / 32 lanes pairwise distinct modulo the group size --
+// what an ideal dealing of a wave's events over its lanes would reach.  (Patterns 6-8 above compute `it % 7`, `it / 7` per
+// operation and are bound by that arithmetic, not by the LDS.)
+template <typename T, int MODE, bool ATOMIC>
+__global__ void k_taps(T* out, int iters)
+{
+	__shared__ T lds[LDS_ELEMS + 7 * 41];
+	for (int i = threadIdx.x; i < LDS_ELEMS + 7 * 41; i += blockDim.x) lds[i] = T(1);
+	__syncthreads();
+	unsigned rnd = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+	T acc = T(0);
+	for (int ev = 0; ev < iters / 49; ++ev)
+	{
+		rnd = rnd * 1664525u + 1013904223u;
+		unsigned base = (rnd >> 10) & (LDS_ELEMS - 1);
+		if (MODE == 1) base = (base & ~15u) | (threadIdx.x & 15u);
+		if (MODE == 2) base = (base & ~31u) | (threadIdx.x & 31u);
+		T* p = lds + base;
+#pragma unroll
+		for (int j = 0; j < 7; ++j)
+		{
+#pragma unroll
+			for (int i = 0; i < 7; ++i)
+			{
+				if (ATOMIC)
+				{
+					atomicAdd(p + j * 41 + i, T(1));
+				}
+				else
+				{
+					acc += __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + j * 41 + i),
+																 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (acc == T(12345)) out[blockIdx.x] = acc + lds[threadIdx.x];
+}
+
 // plain 8-byte LDS reads with the same address patterns (the gather pass)
 template <int PATTERN>
 __global__ void k_read(double* out, int iters)
@@ -172,7 +213,13 @@ int main(int argc, char** argv)
 		run("ds_read_b64 random", k_read<1>, blocks, threads, nullptr);
 		run("ds_read_b64 7-lane groups", k_read<5>, blocks, threads, nullptr);
 		run("ds_read_b64 random base + tap", k_read<6>, blocks, threads, nullptr);
-		// what an ideal dealing of a wave's events over its lanes would reach: bases distinct mod 16 (32) in a lane group
+		run("7x7 taps ds_add_u64, any base", k_taps<unsigned long long, 0, true>, blocks, threads, nullptr);
+		run("7x7 taps ds_add_u64, distinct mod 16", k_taps<unsigned long long, 1, true>, blocks, threads, nullptr);
+		run("7x7 taps ds_add_u64, distinct mod 32", k_taps<unsigned long long, 2, true>, blocks, threads, nullptr);
+		run("7x7 taps ds_read_b64, any base", k_taps<unsigned long long, 0, false>, blocks, threads, nullptr);
+		run("7x7 taps ds_read_b64, distinct mod 16", k_taps<unsigned long long, 1, false>, blocks, threads, nullptr);
+		run("7x7 taps ds_read_b64, distinct mod 32", k_taps<unsigned long long, 2, false>, blocks, threads, nullptr);
+		// (patterns 7 / 8: bound by their own index arithmetic, kept for reference)
 		run("ds_add_u64 base+tap, distinct mod 16", k_atomic<unsigned long long, 7>, blocks, threads, nullptr);
 		run("ds_add_u64 base+tap, distinct mod 32", k_atomic<unsigned long long, 8>, blocks, threads, nullptr);
 		run("ds_read_b64 base+tap, distinct mod 16", k_read<7>, blocks, threads, nullptr);
