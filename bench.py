@@ -176,20 +176,24 @@ def cpu_baseline_all_cores(cfg_idx, seconds):
 # --------------------------------------------------------------------------------------------
 # launcher
 # --------------------------------------------------------------------------------------------
-LDS_PEAK_GOPS = {"ds_add_u64_random": 3479.0, "ds_read_b64_random": 5741.0}  # round-2 microbenchmark (fallback only)
+LDS_PEAK_GOPS = {"ds_add_u64_random": 4335.0, "ds_read_b64_random": 8070.0}  # profiles/r04_lds_rates.txt, "7x7 taps, any base" (fallback only)
 
 
 def lds_roofline(event_evals, kern_ms, rates=None):
     """The LDS-side bound of one value+Jacobian evaluation launch: time the scatter's atomics and the
-    gather's reads would take at the LDS rates measured IN THIS RUN on this GPU (ebo_lds_rates: the
-    loops of tools/microbench/lds_atomics.hip at random addresses), against the measured launch."""
+    gather's reads would take at the LDS rates measured IN THIS RUN on this GPU (ebo_lds_rates: the kernel's own
+    access shape -- a random base slot per lane, then the 49 taps of a 7 x 7 footprint at immediate offsets, 16 waves per
+    CU; tools/microbench/lds_atomics.hip "7x7 taps, any base"), against the measured launch.  Since round 4's last
+    kernels the probe has that shape; before, it issued ONE random operation per loop trip and read 15-25 % lower,
+    i.e. earlier rounds' lds.frac figures are that much too high against this yardstick."""
     peaks = dict(LDS_PEAK_GOPS) if rates is None else {"ds_add_u64_random": rates[0], "ds_read_b64_random": rates[1]}
     min_ms = (49.0 * event_evals / (peaks["ds_add_u64_random"] * 1e9)
               + 49.0 * event_evals / (peaks["ds_read_b64_random"] * 1e9)) * 1e3
     return {"ops_per_event": {"ds_add_u64": 49, "ds_read_b64": 49}, "peak_Gops": peaks,
             "min_ms": min_ms, "frac": min_ms / kern_ms,
             "source": "measured in this run (ebo_lds_rates)" if rates is not None
-            else "event-based-odomety_amd/tools/microbench/lds_atomics.hip (round-2 figures)"}
+            else "event-based-odomety_amd/tools/microbench/lds_atomics.hip (profiles/r04_lds_rates.txt)",
+            "shape": "random base per lane + 49 taps at immediate offsets (the kernel's own), 16 waves per CU"}
 
 
 def _free_port():

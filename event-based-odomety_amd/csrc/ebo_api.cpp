@@ -1890,7 +1890,7 @@ int ebo_lds_rates(ebo_ctx* c, double* gops)
 	{
 		cus = prop.multiProcessorCount;
 	}
-	const int blocks = 4 * cus, iters = 2048;
+	const int blocks = 4 * cus, iters = 49 * 42;  // 42 footprints per lane
 	int rc = ensure_aux(c, static_cast<size_t>(blocks) * sizeof(double));
 	if (rc)
 	{
@@ -1898,7 +1898,7 @@ int ebo_lds_rates(ebo_ctx* c, double* gops)
 	}
 	for (int kind = 0; kind < 2 && rc == EBO_OK; ++kind)
 	{
-		if (launch_lds_rate(kind == 0, blocks, 16, static_cast<double*>(c->d_aux), c->stream))  // warm-up
+		if (launch_lds_rate(kind == 0, blocks, 49, static_cast<double*>(c->d_aux), c->stream))  // warm-up
 		{
 			return c->fail(EBO_ERR_HIP, "k_lds_rate launch failed");
 		}

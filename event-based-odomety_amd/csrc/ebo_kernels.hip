@@ -2171,32 +2171,43 @@ __global__ void k_count_stray(const uint64_t* __restrict__ events, const Unit* _
 	}
 }
 
-// LDS rates at random addresses, measured in the run that quotes them (bench.py's roofline.lds; the same loops as
-// tools/microbench/lds_atomics.hip, patterns "random"): every lane issues `iters` 64-bit LDS atomic adds (ATOMIC) or
-// 64-bit LDS reads at pseudo-random slots of a 32 KB array, 4 workgroups of 256 lanes per CU.
+// LDS rates in the evaluation kernels' own access shape, measured in the run that quotes them (bench.py's roofline.lds;
+// the same loop as tools/microbench/lds_atomics.hip, "7x7 taps ..., any base"): per "event" a pseudo-random base slot per
+// lane, then the 49 taps of a 7 x 7 footprint at immediate offsets (row pitch 41 slots) as 64-bit LDS atomic adds (ATOMIC)
+// or single 64-bit LDS reads -- what k_eval3's scatter and gather issue.  `iters` operations per lane (a multiple of 49),
+// 4 workgroups of 256 lanes per CU.  (Rounds 1-3 probed ONE random operation per loop trip with the generator in between,
+// a latency-bound figure 15-25 % below these.)
 template <bool ATOMIC>
 __global__ void __launch_bounds__(256) k_lds_rate(double* __restrict__ sink, int iters)
 {
-	constexpr int kElems = 4096;
-	__shared__ unsigned long long cell[kElems];
-	for (int i = threadIdx.x; i < kElems; i += blockDim.x)
+	constexpr int kElems = 4096, kPitch = 41;
+	__shared__ unsigned long long cell[kElems + 7 * kPitch];
+	for (int i = threadIdx.x; i < kElems + 7 * kPitch; i += blockDim.x)
 	{
 		cell[i] = static_cast<unsigned long long>(i);
 	}
 	__syncthreads();
 	unsigned rnd = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
 	unsigned long long acc = 0;
-	for (int it = 0; it < iters; ++it)
+	for (int ev = 0; ev < iters / 49; ++ev)
 	{
 		rnd = rnd * 1664525u + 1013904223u;
-		const unsigned a = (rnd >> 10) & (kElems - 1);
-		if (ATOMIC)
+		unsigned long long* p = cell + ((rnd >> 10) & (kElems - 1));
+#pragma unroll
+		for (int j = 0; j < 7; ++j)
 		{
-			atomicAdd(&cell[a], 1ull);
-		}
-		else
-		{
-			acc += cell[a];
+#pragma unroll
+			for (int i = 0; i < 7; ++i)
+			{
+				if (ATOMIC)
+				{
+					atomicAdd(p + j * kPitch + i, 1ull);
+				}
+				else
+				{
+					acc += __hip_atomic_load(p + j * kPitch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // one ds_read_b64 (lds_ld)
+				}
+			}
 		}
 	}
 	__syncthreads();

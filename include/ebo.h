@@ -399,10 +399,11 @@ int ebo_route_events(ebo_ctx* ctx, int n_patches, const double* rects, const uin
  * evaluation's (r, J) go to the context's own result buffer. */
 int ebo_edge_work_stats(ebo_ctx* ctx, const double* d_flows, int want_jac, uint64_t* out);
 
-/* Diagnostic (bench.py's roofline.lds): the chip-wide rates of 64-bit LDS atomic adds (gops[0]) and 64-bit LDS reads
- * (gops[1]) at random addresses, in 1e9 operations per second, measured NOW on the context's device with the loops
- * of tools/microbench/lds_atomics.hip (4 workgroups of 256 lanes per CU, 2048 operations per lane, best of three):
- * the rates the scatter and the gather pass of the variance evaluation are priced against.  Synchronous. */
+/* Diagnostic (bench.py's roofline.lds): the chip-wide rates of 64-bit LDS atomic adds (gops[0]) and single 64-bit LDS reads
+ * (gops[1]) in the evaluation kernels' own access shape -- per lane a random base slot, then the 49 taps of a 7 x 7 footprint
+ * at immediate offsets --, in 1e9 operations per second, measured NOW on the context's device (4 workgroups of 256 lanes
+ * per CU, 42 footprints per lane, best of three; tools/microbench/lds_atomics.hip "7x7 taps, any base"): the rates the
+ * scatter and the gather pass of the variance evaluation are priced against.  Synchronous. */
 int ebo_lds_rates(ebo_ctx* ctx, double* gops);
 
 /* Diagnostic (bench.py): the traffic of ebo_count_image_device with no work -- every packed event of the
