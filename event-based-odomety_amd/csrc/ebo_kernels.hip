@@ -1910,8 +1910,10 @@ __device__ __forceinline__ void tile_pass(const uint64_t* __restrict__ events, c
 	EDGE_TICK(17);
 	const int lane = threadIdx.x & 63;
 	const float scalef = static_cast<float>(c.scale);
-	constexpr int kInFlight = 4;
-	// Software pipeline: the loads of the NEXT batch of 256 events (the same unit's, or the first
+	// six 8-byte loads per lane and batch (round 4, end: 4 -> 6 is +1 point of HBM fraction at every size, 7 is mixed, 8 takes
+	// the kernel over 64 VGPRs = one workgroup per CU; 16-byte loads are 3-5 points SLOWER: profiles/r04_count_*_ab.txt)
+	constexpr int kInFlight = 6;
+	// Software pipeline: the loads of the NEXT batch of 384 events (the same unit's, or the first
 	// of the next unit the wave picks) are in flight while the current batch is counted.
 	// what a wave needs of a unit, fetched when the unit is PICKED (one batch ahead of its use):
 	// header, flow (f64 and float) and the float pre-test's tolerances -- all wave-uniform
