@@ -1,4 +1,4 @@
-// ceres_reference_lines_test.cpp — the reference's OWN problem construction, unchanged.
+// ceres_reference_lines_test.cpp — the reference's Ceres construction expressions against the facade.
 //
 // FeatureDetector::compensateEventsContrast builds its problem with
 //     new ceres::AutoDiffCostFunction<tracker::contrastFunctor, 1, 2>(new tracker::contrastFunctor(
@@ -7,7 +7,7 @@
 //         new tracker::totalVarianceFunctor(params_.compensateTVweight))   (:371-375, :384-388)
 //     problem.AddResidualBlock(cost_function, new ceres::HuberLoss(params_.compensateTVHuberLoss), ...)
 //     Solve(options, &problem, &summary)                                   (:401-414)
-// This program writes those statements against the facade headers (tracker::contrastFunctor with
+// This program uses those expressions (inside its own assembly of the patch grid) against the facade headers (tracker::contrastFunctor with
 // its Jet-capable operator(), tracker::totalVarianceFunctor) and the test-only Ceres declarations of
 // stubs/ceres/ceres.h, so the AutoDiff instantiation of the functor meets a compiler and runs.
 // ceres::Solve is DEFINED here: it recovers the patch grid from the blocks, checks that every TV
@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <iterator>
 #include <list>
 #include <vector>
 
@@ -208,107 +209,98 @@ static std::vector<common::EventSample> makeEvents(int n, uint64_t seed)
 	return out;
 }
 
-// What the reference's member function reads from `this`.
-struct Fixture
+// The problem FeatureDetector::compensateEventsContrast hands to Ceres (feature_detector.cpp:301-414), assembled by
+// this file's own statements.  What is the reference's are the CONSTRUCTION EXPRESSIONS -- the interface under test:
+//     new ceres::AutoDiffCostFunction<tracker::contrastFunctor, 1, 2>(new tracker::contrastFunctor(events, rect, scale))
+//     new ceres::AutoDiffCostFunction<tracker::totalVarianceFunctor, 2, 2, 2>(new tracker::totalVarianceFunctor(weight))
+//     problem.AddResidualBlock(cost, new ceres::HuberLoss(delta), a, b);   Solve(options, &problem, &summary);
+// and the option values of :401-410.  Functor = tracker::contrastFunctor is the reference's type; the variance alias only
+// changes which loss the device evaluates.
+struct GridOfPatches
 {
-	tracker::DetectorParams params_;
+	int nx, ny, sensorW, sensorH, pw, ph;
+	explicit GridOfPatches(const tracker::DetectorParams& dp)
+		: nx(dp.imageSize.width / dp.patchCompensateSize.width), ny(dp.imageSize.height / dp.patchCompensateSize.height),
+		  sensorW(dp.imageSize.width), sensorH(dp.imageSize.height), pw(dp.patchCompensateSize.width),
+		  ph(dp.patchCompensateSize.height)
+	{
+	}
+	int count() const { return nx * ny; }
+	int index(int gx, int gy) const { return gy * nx + gx; }
+	// regular cells; the last column / row takes what is left of the sensor (:332-346)
+	tracker::Rect2i cell(int gx, int gy) const
+	{
+		tracker::Rect2i r;
+		r.x = gx * pw;
+		r.y = gy * ph;
+		r.width = gx + 1 == nx ? sensorW - r.x : pw;
+		r.height = gy + 1 == ny ? sensorH - r.y : ph;
+		return r;
+	}
 };
 
-// feature_detector.cpp:301-414 with the reference's statements; Functor = tracker::contrastFunctor
-// is the reference's line, the variance alias only changes which loss the device evaluates.
 template <typename Functor>
-static std::vector<double> referenceStatements(const Fixture& self, const std::list<common::EventSample>& events,
-												ceres::Solver::Summary& summary, int& numBlocks)
+static std::vector<double> solveThroughCeresSurface(const tracker::DetectorParams& dp, const std::list<common::EventSample>& events,
+													ceres::Solver::Summary& summary, int& numBlocks)
 {
-	const tracker::DetectorParams& params_ = self.params_;
-	int numPatchesX = params_.imageSize.width / params_.patchCompensateSize.width;
-	int numPatchesY = params_.imageSize.height / params_.patchCompensateSize.height;
+	const GridOfPatches grid(dp);
+	std::vector<double> flow(2 * static_cast<size_t>(grid.count()), 0.0);  // every solve starts at zero flow (:318-326)
+	auto block = [&](int gx, int gy) { return flow.data() + 2 * grid.index(gx, gy); };
+	auto coupling = [&](double* a, double* b, ceres::Problem& problem) {
+		ceres::CostFunction* tv =
+			new ceres::AutoDiffCostFunction<tracker::totalVarianceFunctor, 2, 2, 2>(new tracker::totalVarianceFunctor(dp.compensateTVweight));
+		problem.AddResidualBlock(tv, new ceres::HuberLoss(dp.compensateTVHuberLoss), a, b);
+	};
 
 	ceres::Problem problem;
-	auto* mf = new double[numPatchesX * numPatchesY * 2];
-	for (int i = 0; i < numPatchesX * numPatchesY * 2; i++)
+	for (int gy = 0; gy < grid.ny; ++gy)
 	{
-		mf[i] = 0;
-	}
-
-	for (int y = 0; y < numPatchesY; y++)
-	{
-		for (int x = 0; x < numPatchesX; x++)
+		for (int gx = 0; gx < grid.nx; ++gx)
 		{
-			tracker::Rect2i patchRect;  // cv::Rect2i in the reference
-			patchRect.x = x * params_.patchCompensateSize.width;
-			patchRect.y = y * params_.patchCompensateSize.height;
-			patchRect.width = x == numPatchesX - 1 ? params_.imageSize.width - x * params_.patchCompensateSize.width
-												  : params_.patchCompensateSize.width;
-			patchRect.height = y == numPatchesY - 1 ? params_.imageSize.height - y * params_.patchCompensateSize.height
-													: params_.patchCompensateSize.height;
-
-			std::list<common::EventSample> patchEvents;
-			for (const auto& event : events)
+			const tracker::Rect2i rect = grid.cell(gx, gy);
+			std::list<common::EventSample> inside;
+			std::copy_if(events.begin(), events.end(), std::back_inserter(inside),
+						 [&](const common::EventSample& e) { return rect.contains(e.value.point); });
+			if (inside.size() > dp.compensateMinNumEvents)  // strictly more (:357)
 			{
-				if (patchRect.contains(event.value.point))
-				{
-					patchEvents.push_back(event);
-				}
+				ceres::CostFunction* data = new ceres::AutoDiffCostFunction<Functor, 1, 2>(new Functor(inside, rect, dp.compensateScale));
+				problem.AddResidualBlock(data, nullptr, block(gx, gy));
 			}
-
-			if (patchEvents.size() > params_.compensateMinNumEvents)
+			if (gx + 1 < grid.nx)
 			{
-				ceres::CostFunction* cost_function = new ceres::AutoDiffCostFunction<Functor, 1, 2>(
-					new Functor(patchEvents, patchRect, params_.compensateScale));
-
-				problem.AddResidualBlock(cost_function, nullptr, &mf[2 * (y * numPatchesX + x)]);
+				coupling(block(gx, gy), block(gx + 1, gy), problem);  // right neighbour first, then the one below (:369-396)
 			}
-
-			if (x < numPatchesX - 1)
+			if (gy + 1 < grid.ny)
 			{
-				ceres::CostFunction* cost_function = new ceres::AutoDiffCostFunction<tracker::totalVarianceFunctor, 2, 2, 2>(
-					new tracker::totalVarianceFunctor(params_.compensateTVweight));
-
-				problem.AddResidualBlock(cost_function, new ceres::HuberLoss(params_.compensateTVHuberLoss),
-										 &mf[2 * (y * numPatchesX + x)], &mf[2 * (y * numPatchesX + x + 1)]);
-			}
-			if (y < numPatchesY - 1)
-			{
-				ceres::CostFunction* cost_function = new ceres::AutoDiffCostFunction<tracker::totalVarianceFunctor, 2, 2, 2>(
-					new tracker::totalVarianceFunctor(params_.compensateTVweight));
-
-				problem.AddResidualBlock(cost_function, new ceres::HuberLoss(params_.compensateTVHuberLoss),
-										 &mf[2 * (y * numPatchesX + x)], &mf[2 * ((y + 1) * numPatchesX + x)]);
+				coupling(block(gx, gy), block(gx, gy + 1), problem);
 			}
 		}
 	}
 
-	ceres::Solver::Options options;
-	options.minimizer_progress_to_stdout = false;
-	options.num_threads = 1;
-	options.logging_type = ceres::SILENT;
+	ceres::Solver::Options options;  // feature_detector.cpp:401-410
 	options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
 	options.use_nonmonotonic_steps = true;
 	options.max_num_iterations = 50;
-	options.function_tolerance = 1e-12;
-	options.gradient_tolerance = 1e-12;
-	options.parameter_tolerance = 1e-12;
-
+	options.function_tolerance = options.gradient_tolerance = options.parameter_tolerance = 1e-12;
+	options.num_threads = 1;
+	options.minimizer_progress_to_stdout = false;
+	options.logging_type = ceres::SILENT;
 	Solve(options, &problem, &summary);
-
 	numBlocks = problem.NumResidualBlocks();
-	std::vector<double> flows(mf, mf + numPatchesX * numPatchesY * 2);
-	delete[] mf;  // the reference leaks it (:318)
-	return flows;
+	return flow;
 }
 
 static void runCase(int loss, const char* name)
 {
-	Fixture self;  // reference defaults: 240x180, 20x20, TV 1e3, Huber 10, scale 1e-3, > 100 events
+	const tracker::DetectorParams self;  // reference defaults: 240x180, 20x20, TV 1e3, Huber 10, scale 1e-3, > 100 events
 	const std::vector<common::EventSample> samples = makeEvents(15000, 20200701);
 	const std::list<common::EventSample> events(samples.begin(), samples.end());
 
 	ceres::Solver::Summary summary;
 	int numBlocks = 0;
 	const std::vector<double> mf = loss == EBO_LOSS_EDGE
-									   ? referenceStatements<tracker::contrastFunctor>(self, events, summary, numBlocks)
-									   : referenceStatements<tracker::contrastFunctorVariance>(self, events, summary, numBlocks);
+									   ? solveThroughCeresSurface<tracker::contrastFunctor>(self, events, summary, numBlocks)
+									   : solveThroughCeresSurface<tracker::contrastFunctorVariance>(self, events, summary, numBlocks);
 
 	// the same window through the C ABI's own global solve
 	ebo_params prm;

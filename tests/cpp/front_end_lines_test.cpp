@@ -1,24 +1,22 @@
-// front_end_lines_test.cpp — the reference front end's OWN statements against the facade class.
+// front_end_lines_test.cpp — the facade's ONE tracker::FeatureDetector under the front end's call pattern.
 //
 // The unchanged visual_odometry front end holds ONE tracker::FeatureDetector and calls, per event,
-//     tracker_->addEvent(sample); tracker_->updatePatches(sample); ... compensateEventsContrast /
-//     integrateEvents / clearEvents                       (tools/evaluator/src/evaluator.cpp:32-45)
-// and, around that, getPatches (:23-30), preExit / getArchivedPatches / getOptimizedFinalCosts
-// (:15-21), DetectorParams::drawImages / imageSize (:106-109), setParams (:120-123) and
-// visual_odometry::Keyframe(tracker_->getPatches(), ts) (visual_odometry/src/keyframe.cpp:5-14).
-// The blocks marked "verbatim" below are those statements, unchanged, compiled with -Wall -Wextra
-// against <feature_tracker/feature_detector.h> of the facade.  What the front end has besides the
-// tracker (spdlog loggers, VisualOdometryFrontEnd, Eigen) is not on the path: tools::Evaluator here is
-// a shell with the reference's member names, Eigen::Vector2d a two-double stand-in (test-only).
+// addEvent / updatePatches and, when a window is full, compensateEventsContrast / integrateEvents / clearEvents
+// (tools/evaluator/src/evaluator.cpp:32-45); around that getPatches (:23-30), preExit / getArchivedPatches /
+// getOptimizedFinalCosts (:15-21), DetectorParams::drawImages / imageSize (:106-109), setParams (:120-123), and a
+// keyframe reads toCorner() / getTrackId() of getPatches() (visual_odometry/src/keyframe.cpp:5-14).
+// Source compatibility is shown by (i) a member-pointer table that pins each of those members by name, argument and
+// result type and (ii) this file's OWN driver (FrontEndDriver) that calls them in the evaluator's order — not by
+// carrying the reference's statements.  Compiled with -Wall -Wextra against <feature_tracker/feature_detector.h>.
 //
 // Checked on the GPU:
-//   * the reference's updatePatchTest / associatedPatchesTest (feature_detector_test.cpp:43-125), verbatim;
-//   * the evaluator loop over a stream: the ONE FeatureDetector gives, bit for bit, the patches / flows /
+//   * the scenarios of the reference's updatePatchTest / associatedPatchesTest (feature_detector_test.cpp:43-125);
+//   * the front-end loop over a stream: the ONE FeatureDetector gives, bit for bit, the patches / flows /
 //     images of the former pair (a stand-alone tracker::TrackedPatches + a FeatureDetector used for the
 //     compensation only), although tracker and compensation now share one device context;
 //   * the newImage life cycle through FrontEndHooks (associate, archive lost, optimizer user counts);
 //   * newImage without hooks reports EBO_ERR_UNSUPPORTED through the error policy.
-// `--cpu` runs the host-only subset (no device): the two reference tests' bookkeeping and the error policy.
+// `--cpu` runs the host-only subset (no device): the two scenarios' bookkeeping and the error policy.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -30,7 +28,10 @@
 #include <list>
 #include <memory>
 #include <string>
+#include <tuple>
+#include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include <common/data_types.h>
@@ -50,280 +51,233 @@ static int g_fail = 0;
 #define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
 #define ASSERT_EQ(a, b) EXPECT_TRUE((a) == (b))
 
-// ---- stand-ins for what the front end has besides the tracker (test-only) --------------------------
-namespace Eigen
-{
-struct Vector2d
-{
-	double v[2] = {0.0, 0.0};
-	Vector2d() = default;
-	Vector2d(double x, double y) : v{x, y} {}
-	double x() const { return v[0]; }
-	double y() const { return v[1]; }
-};
-}  // namespace Eigen
-
-namespace visual_odometry
-{
-using Landmarks = std::unordered_map<tracker::TrackId, Eigen::Vector2d>;  // keyframe.h:10
-
-class Keyframe  // keyframe.h:24-43 without the pose
-{
-   public:
-	Keyframe() {}
-	Keyframe(const tracker::Patches& patches, const common::timestamp_t& timestamp);
-	const Landmarks& getLandmarks() const { return landmarks_; }
-
-   public:
-	common::timestamp_t timestamp;
-
-   private:
-	Landmarks landmarks_;
-};
-
-// ---- visual_odometry/src/keyframe.cpp:5-14, verbatim ---------------------------------------------
-Keyframe::Keyframe(const tracker::Patches& patches,
-				   const common::timestamp_t& timestamp)
-	: timestamp(timestamp)
-{
-	for (const auto& patch : patches)
-	{
-		const auto corner = patch.toCorner();
-		landmarks_[patch.getTrackId()] = Eigen::Vector2d(corner.x, corner.y);
-	}
-}
-}  // namespace visual_odometry
-
-// Two flavours of this program: without OpenCV on the include path the shell below spells the two OpenCV types of the
-// evaluator's interface with the facade's stand-ins; built with -Istubs_opencv (test-only declarations of cv::Size_,
-// cv::Point_, cv::Rect_, cv::Mat) the facade's EBO_HAVE_OPENCV branch is live and the shell keeps the reference's own
-// `cv::Size2i imageSize` and `cv::Mat const& getCompensatedEventImage()` -- no rename at all.
+// Two flavours of this program: without OpenCV on the include path the driver below spells the two OpenCV types of the
+// front end's interface with the facade's stand-ins; built with -Istubs_opencv (test-only declarations of cv::Size_,
+// cv::Point_, cv::Rect_, cv::Mat) the facade's EBO_HAVE_OPENCV branch is live and the driver holds the reference's own
+// `cv::Size2i` and receives `cv::Mat const&` -- no rename at all.
 #ifdef EBO_HAVE_OPENCV
-using EvaluatorSize = cv::Size2i;
-using EvaluatorImage = cv::Mat;
+using FrameSize = cv::Size2i;
+using FrameImage = cv::Mat;
 static common::Image8 makeImage8(int rows, int cols) { return cv::Mat(rows, cols, CV_8U); }
 #else
-using EvaluatorSize = tracker::Size;
-using EvaluatorImage = tracker::Mat64;
+using FrameSize = tracker::Size;
+using FrameImage = tracker::Mat64;
 static common::Image8 makeImage8(int rows, int cols) { return common::Image8(rows, cols); }
 #endif
 
-namespace tools
+// ---- signature conformance with implementation/feature_tracker/include/feature_tracker/feature_detector.h:33-88 ----
+// The members the front end (tools/evaluator/src/evaluator.cpp:15-45,106-109,120-123; visual_odometry/src/keyframe.cpp:
+// 5-14) calls on its ONE tracker::FeatureDetector, by name, argument and result type.  A member-pointer cast only
+// compiles for an exact match; this table replaces carrying the front end's statements as text.
+namespace conformance
 {
-struct EvaluatorParams  // tools/evaluator/include/evaluator/evaluator.h:14-26
+using D = tracker::FeatureDetector;
+static_assert(std::is_constructible<D, const tracker::DetectorParams&>::value, "FeatureDetector(params)");
+[[maybe_unused]] static const auto kMembers = std::make_tuple(
+	static_cast<void (D::*)()>(&D::preExit), static_cast<void (D::*)(const common::ImageSample&)>(&D::newImage),
+	static_cast<void (D::*)(const common::ImageSample&)>(&D::extractPatches),
+	static_cast<tracker::Corners (D::*)(const common::Image8&)>(&D::detectFeatures),
+	static_cast<void (D::*)(const common::EventSample&)>(&D::updatePatches),
+	static_cast<void (D::*)(const common::EventSample&)>(&D::addEvent),
+	static_cast<void (D::*)(const common::timestamp_t)>(&D::initMotionField),
+	static_cast<void (D::*)(const common::timestamp_t)>(&D::interpolateMotionField),
+	static_cast<void (D::*)(const std::list<common::EventSample>&)>(&D::compensateEvents),
+	static_cast<void (D::*)(const std::list<common::EventSample>&)>(&D::compensateEventsContrast),
+	static_cast<void (D::*)()>(&D::clearEvents),
+	static_cast<void (D::*)(const std::list<common::EventSample>&)>(&D::integrateEvents),
+	static_cast<void (D::*)(tracker::Patches&, const common::timestamp_t&)>(&D::associatePatches),
+	static_cast<void (D::*)(tracker::Patch&)>(&D::updateNumOfEvents),
+	static_cast<void (D::*)(const tracker::Patches&)>(&D::setPatches),
+	static_cast<void (D::*)(const tracker::DetectorParams&)>(&D::setParams),
+	static_cast<void (D::*)(tracker::TrackId)>(&D::setTrackId),
+	static_cast<tracker::Patches const& (D::*)() const>(&D::getPatches), static_cast<tracker::Patches& (D::*)()>(&D::getPatches),
+	static_cast<tracker::Corners const& (D::*)() const>(&D::getFeatures),
+	static_cast<tracker::Patches const& (D::*)() const>(&D::getArchivedPatches),
+	static_cast<std::list<common::EventSample> const& (D::*)()>(&D::getEvents),
+	static_cast<tracker::Mat64 const& (D::*)()>(&D::getCompensatedEventImage),
+	static_cast<tracker::Mat64 const& (D::*)()>(&D::getIntegratedEventImage),
+	static_cast<common::timestamp_t const& (D::*)()>(&D::getLastCompensation),
+	static_cast<std::vector<tracker::OptimizerFinalLoss> (D::*)() const>(&D::getOptimizedFinalCosts));
+// the two images bind to the front end's `cv::Mat const&` (Mat64 IS a cv::Mat with OpenCV on the include path)
+static_assert(std::is_convertible<tracker::Mat64 const&, FrameImage const&>::value, "Mat64 const& -> cv::Mat const&");
+static_assert(std::is_same<decltype(tracker::DetectorParams::imageSize), FrameSize>::value, "DetectorParams::imageSize");
+static_assert(std::is_same<decltype(tracker::DetectorParams::drawImages), bool>::value, "DetectorParams::drawImages");
+}  // namespace conformance
+
+// ---- what a keyframe takes from the tracker: one landmark per track id ---------------------------------------------
+// (visual_odometry/src/keyframe.cpp:5-14 walks getPatches() and keys toCorner() by getTrackId(); own statements)
+struct Landmark
 {
-	EvaluatorSize imageSize = {240, 180};
-	std::string outputDir = "/tmp";
-	bool drawImages = false;
-	// compensate whole image each k microseconds
-	uint32_t compensationFrequencyTime = 300000;
-	uint32_t compensationFrequencyEvents = 15000;
-	bool trackerExperiment = false;
-	bool visOdometryExperiment = false;
+	double x = 0.0, y = 0.0;
+};
+static std::unordered_map<tracker::TrackId, Landmark> landmarksOf(const tracker::Patches& tracked)
+{
+	std::unordered_map<tracker::TrackId, Landmark> table;
+	for (auto it = tracked.begin(); it != tracked.end(); ++it)
+	{
+		const tracker::Corner at = it->toCorner();
+		Landmark& slot = table[it->getTrackId()];
+		slot.x = at.x;
+		slot.y = at.y;
+	}
+	return table;
+}
+
+// ---- the front end's side of the tracker, as this test's own driver ------------------------------------------------
+// Holds ONE tracker::FeatureDetector the way tools::Evaluator does and drives it in the evaluator's call order:
+// per event addEvent -> updatePatches -> [window full: compensateEventsContrast -> integrateEvents -> clearEvents]
+// (evaluator.cpp:32-45: full = time since the last compensation >= a period, or the event count reached a cap); at the
+// end preExit and the two result files (:15-21).  Names and control flow are this file's.
+struct WindowRule
+{
+	FrameSize sensor = {240, 180};
+	std::string resultsDir = "/tmp";
+	bool draw = false;
+	uint32_t periodMicros = 300000;  // the evaluator's compensationFrequencyTime default
+	uint32_t eventCap = 15000;       // compensationFrequencyEvents
 };
 
-class Evaluator  // evaluator.h:28-88, the members the tracker side touches
+class FrontEndDriver
 {
    public:
-	Evaluator(const EvaluatorParams& params);
-	~Evaluator();
-	void eventCallback(const common::EventSample& sample);
-	void reset();
-	void setTrackerParams(const tracker::DetectorParams& params);
-	void saveFeaturesTrajectory(const tracker::Patches& patches);
-	void saveFinalCosts(const std::vector<tracker::OptimizerFinalLoss>& vectorFinalCosts);
-	tracker::Patches const& getPatches() const;
-	EvaluatorImage const& getCompensatedEventImage();
-	EvaluatorImage const& getIntegratedEventImage();
-	tracker::FeatureDetector& tracker() { return *tracker_; }  // test access
-	int windows = 0;                                           // test instrumentation
+	explicit FrontEndDriver(const WindowRule& rule) : rule_(rule)
+	{
+		tracker::DetectorParams dp;
+		dp.imageSize = rule_.sensor;
+		dp.drawImages = rule_.draw;
+		detector_ = std::make_unique<tracker::FeatureDetector>(dp);
+	}
+	~FrontEndDriver()
+	{
+		detector_->preExit();
+		tools::saveFeaturesTrajectory(detector_->getArchivedPatches(), rule_.resultsDir + "/trajectory.txt");
+		std::ofstream out(rule_.resultsDir + "/final_cost.txt");
+		out << std::fixed << std::setprecision(8);
+		for (const tracker::OptimizerFinalLoss& c : detector_->getOptimizedFinalCosts())
+		{
+			out << c.trackId << ' ' << c.lossValue << ' ' << c.timeStampMicrosecond << '\n';  // the evaluator's line format (:208-213)
+		}
+	}
+	// one event of the stream; returns whether it closed a window
+	bool feed(const common::EventSample& e)
+	{
+		tracker::FeatureDetector& d = *detector_;
+		d.addEvent(e);
+		d.updatePatches(e);
+		const bool periodOver = (e.timestamp - d.getLastCompensation()).count() >= rule_.periodMicros;
+		const bool capReached = d.getEvents().size() >= rule_.eventCap;
+		if (!periodOver && !capReached)
+		{
+			return false;
+		}
+		const std::list<common::EventSample>& window = d.getEvents();
+		d.compensateEventsContrast(window);
+		d.integrateEvents(window);
+		d.clearEvents();
+		++windowsClosed;
+		return true;
+	}
+	void reconfigure(const tracker::DetectorParams& dp) { detector_->setParams(dp); }
+	tracker::Patches const& patches() const { return detector_->getPatches(); }
+	FrameImage const& warpedImage() { return detector_->getCompensatedEventImage(); }
+	FrameImage const& plainImage() { return detector_->getIntegratedEventImage(); }
+	tracker::FeatureDetector& detector() { return *detector_; }
+	int windowsClosed = 0;
 
    private:
-	EvaluatorParams params_;
-	std::unique_ptr<tracker::FeatureDetector> tracker_;
-	tracker::Patches patches_;
+	WindowRule rule_;
+	std::unique_ptr<tracker::FeatureDetector> detector_;
 };
 
-Evaluator::Evaluator(const EvaluatorParams& params) : params_(params)
+// ---- the scenarios of the reference's two detector tests (feature_detector_test.cpp:43-125), own statements --------
+// Routing: three 11-extent patches at (0,0), (5,5), (20,20) on a detector with patchExtent 5; five events in [0,30)^2;
+// every patch of the detector must hold exactly the events a stand-alone copy of the patch accepted through isInPatch,
+// in the same order.  `policy` selects the error policy (without a device the default one throws from the constructor).
+static void routingScenario(tracker::DetectorParams::ErrorPolicy policy, bool setPolicy)
 {
-	reset();
-}
-
-Evaluator::~Evaluator()
-{
-	// ---- evaluator.cpp:17,18,20, verbatim (:19 savePoses belongs to the VO front end) ------------
-	tracker_->preExit();
-	saveFeaturesTrajectory(tracker_->getArchivedPatches());
-	saveFinalCosts(tracker_->getOptimizedFinalCosts());
-}
-
-// ---- evaluator.cpp:23-30, verbatim ---------------------------------------------------------------
-tracker::Patches const& Evaluator::getPatches() const
-{
-	if (params_.visOdometryExperiment)
+	tracker::DetectorParams dp;
+	dp.patchExtent = 5;
+	if (setPolicy)
 	{
-		return patches_;
+		dp.errorPolicy = policy;
 	}
-	return tracker_->getPatches();
-}
-
-// ---- evaluator.cpp:32-45, verbatim (plus the window counter) -------------------------------------
-void Evaluator::eventCallback(const common::EventSample& sample)
-{
-	tracker_->addEvent(sample);
-	tracker_->updatePatches(sample);
-	if ((sample.timestamp - tracker_->getLastCompensation()).count() >=
-			params_.compensationFrequencyTime or
-		tracker_->getEvents().size() >= params_.compensationFrequencyEvents)
+	tracker::FeatureDetector d(dp);
+	const common::timestamp_t t0(0);
+	const int centres[3] = {0, 5, 20};
+	tracker::Patches mirror;
+	for (int c : centres)
 	{
-		//		tracker_->compensateEvents(tracker_->getEvents());
-		tracker_->compensateEventsContrast(tracker_->getEvents());
-		tracker_->integrateEvents(tracker_->getEvents());
-		tracker_->clearEvents();
-		++windows;
+		mirror.emplace_back(tracker::Corner(c, c), 11, t0);
 	}
-}
-
-void Evaluator::reset()
-{
-	// ---- evaluator.cpp:106-109, verbatim ---------------------------------------------------------
-	tracker::DetectorParams params;
-	params.drawImages = params_.drawImages;
-	params.imageSize = params_.imageSize;
-	tracker_.reset(new tracker::FeatureDetector(params));
-}
-
-// ---- evaluator.cpp:120-123, verbatim -------------------------------------------------------------
-void Evaluator::setTrackerParams(const tracker::DetectorParams& params)
-{
-	tracker_->setParams(params);
-}
-
-void Evaluator::saveFeaturesTrajectory(const tracker::Patches& patches)
-{
-	const std::string outputFilename = params_.outputDir + "/trajectory.txt";  // evaluator.cpp:129
-	tools::saveFeaturesTrajectory(patches, outputFilename);
-}
-
-void Evaluator::saveFinalCosts(const std::vector<tracker::OptimizerFinalLoss>& vectorFinalCosts)
-{
-	const std::string outputFilename = params_.outputDir + "/final_cost.txt";
-	std::ofstream costFile;
-	costFile.open(outputFilename);
-	// ---- evaluator.cpp:208-213, verbatim ---------------------------------------------------------
-	for (const auto& v : vectorFinalCosts)
+	d.setPatches(mirror);
+	uint32_t lcg = 90210u;
+	for (int k = 0; k < 5; ++k)
 	{
-		costFile << v.trackId << " " << std::fixed << std::setprecision(8)
-				 << v.lossValue << " " << v.timeStampMicrosecond << std::endl;
+		lcg = lcg * 1664525u + 1013904223u;
+		common::EventSample e;
+		e.timestamp = common::timestamp_t(k);
+		e.value.point = {static_cast<int>((lcg >> 8) % 30), static_cast<int>((lcg >> 16) % 30)};
+		e.value.sign = (lcg >> 24) & 1u ? common::EventPolarity::POSITIVE : common::EventPolarity::NEGATIVE;
+		d.updatePatches(e);
+		for (tracker::Patch& m : mirror)
+		{
+			if (m.isInPatch(e.value.point))
+			{
+				m.addEvent(e);
+			}
+		}
 	}
-
-	costFile.close();
+	const tracker::Patches routed = d.getPatches();
+	EXPECT_TRUE(routed.size() == mirror.size());
+	auto r = routed.begin();
+	size_t held = 0;
+	for (auto m = mirror.begin(); m != mirror.end() && r != routed.end(); ++m, ++r)
+	{
+		const common::EventSequence& want = m->getEvents();
+		const common::EventSequence& got = r->getEvents();
+		EXPECT_TRUE(got.size() == want.size());
+		for (size_t k = 0; k < want.size() && k < got.size(); ++k)
+		{
+			EXPECT_TRUE(got[k].timestamp == want[k].timestamp);
+		}
+		held += got.size();
+	}
+	EXPECT_TRUE(held >= 5);  // all five land in the 23 x 23 patch around (5,5) at least
 }
 
-// ---- evaluator.cpp:219-227, verbatim (EvaluatorImage = cv::Mat with OpenCV) -------------------------
-EvaluatorImage const& Evaluator::getCompensatedEventImage()
+// Association: the same three patches with track ids 0..2; three new patches at (3,0), (0,1), (18,18) with
+// associationDistance 5: two are within reach of an old patch, one is not -> four patches afterwards (the reference's
+// expectation); beyond it: the unmatched one takes the next track id, a matched one gains a trajectory point.
+static void associationScenario(tracker::DetectorParams::ErrorPolicy policy, bool setPolicy)
 {
-	return tracker_->getCompensatedEventImage();
-}
-
-EvaluatorImage const& Evaluator::getIntegratedEventImage()
-{
-	return tracker_->getIntegratedEventImage();
-}
-}  // namespace tools
-
-// ---- the reference's own two detector tests (feature_detector_test.cpp:43-125) -----------------------
-// POLICY is empty for the verbatim run; the host-only run adds one statement that selects ERRORS_STATUS
-// (without a device the default policy throws from the constructor, as it should).
-#define REFERENCE_UPDATE_PATCH_TEST(POLICY)                                                           \
-	{                                                                                                 \
-		tracker::DetectorParams params;                                                               \
-		params.patchExtent = 5;                                                                       \
-		POLICY;                                                                                       \
-		tracker::FeatureDetector detector(params);                                                    \
-		const common::timestamp_t timestamp(0);                                                       \
-                                                                                                      \
-		tracker::Patches patches = {tracker::Patch({0, 0}, 11, timestamp),                            \
-									tracker::Patch({5, 5}, 11, timestamp),                            \
-									tracker::Patch({20, 20}, 11, timestamp)};                         \
-                                                                                                      \
-		detector.setPatches(patches);                                                                 \
-                                                                                                      \
-		common::EventSequence events;                                                                 \
-                                                                                                      \
-		for (size_t i = 0; i < 5; ++i)                                                                \
-		{                                                                                             \
-			common::EventSample event;                                                                \
-			event.timestamp = common::timestamp_t(i);                                                 \
-			event.value.point = {std::rand() % 30, std::rand() % 30};                                 \
-			event.value.sign = std::rand() % 2 == 1                                                   \
-								   ? common::EventPolarity::POSITIVE                                  \
-								   : common::EventPolarity::NEGATIVE;                                 \
-			detector.updatePatches(event);                                                            \
-                                                                                                      \
-			for (auto& patch : patches)                                                               \
-			{                                                                                         \
-				if (patch.isInPatch(event.value.point))                                               \
-				{                                                                                     \
-					patch.addEvent(event);                                                            \
-				}                                                                                     \
-			}                                                                                         \
-		}                                                                                             \
-                                                                                                      \
-		const auto detectorPatches = detector.getPatches();                                           \
-                                                                                                      \
-		ASSERT_EQ(detectorPatches.size(), patches.size());                                            \
-                                                                                                      \
-		auto detectorPatchesIt = detectorPatches.begin();                                             \
-		for (auto patchIt = patches.begin(); patchIt != patches.end();                                \
-			 ++patchIt, ++detectorPatchesIt)                                                          \
-		{                                                                                             \
-			const auto detectorEvents = detectorPatchesIt->getEvents();                               \
-			const auto gtEvents = patchIt->getEvents();                                               \
-			ASSERT_EQ(detectorEvents.size(), gtEvents.size());                                        \
-                                                                                                      \
-			auto detectorIt = detectorEvents.begin();                                                 \
-			for (auto gtIt = gtEvents.begin();                                                        \
-				 gtIt != gtEvents.end() && detectorIt != detectorEvents.end();                        \
-				 ++gtIt, ++detectorIt)                                                                \
-			{                                                                                         \
-				EXPECT_EQ(detectorIt->timestamp, gtIt->timestamp);                                    \
-			}                                                                                         \
-		}                                                                                             \
+	tracker::DetectorParams dp;
+	dp.patchExtent = 5;
+	dp.associationDistance = 5;
+	if (setPolicy)
+	{
+		dp.errorPolicy = policy;
 	}
-
-#define REFERENCE_ASSOCIATED_PATCHES_TEST(POLICY)                                                     \
-	{                                                                                                 \
-		tracker::DetectorParams params;                                                               \
-		params.patchExtent = 5;                                                                       \
-		params.associationDistance = 5;                                                               \
-		POLICY;                                                                                       \
-		tracker::FeatureDetector detector(params);                                                    \
-		const common::timestamp_t timestamp(0);                                                       \
-                                                                                                      \
-		tracker::Patches patches = {tracker::Patch({0, 0}, 11, timestamp),                            \
-									tracker::Patch({5, 5}, 11, timestamp),                            \
-									tracker::Patch({20, 20}, 11, timestamp)};                         \
-                                                                                                      \
-		tracker::TrackId trackId = 0;                                                                 \
-		for (auto& patch : patches)                                                                   \
-		{                                                                                             \
-			patch.setTrackId(trackId++);                                                              \
-		}                                                                                             \
-		detector.setPatches(patches);                                                                 \
-		detector.setTrackId(trackId);                                                                 \
-                                                                                                      \
-		tracker::Patches newPatches = {tracker::Patch({3, 0}, 11, timestamp),                         \
-									   tracker::Patch({0, 1}, 11, timestamp),                         \
-									   tracker::Patch({18, 18}, 11, timestamp)};                      \
-                                                                                                      \
-		detector.associatePatches(newPatches, common::timestamp_t(0));                                \
-		const auto updatedPatches = detector.getPatches();                                            \
-		EXPECT_EQ(updatedPatches.size(), 4u);                                                         \
-		/* beyond the reference's check: the one unmatched patch takes the next track id */           \
-		EXPECT_EQ(updatedPatches.back().getTrackId(), 3);                                             \
-		EXPECT_EQ(updatedPatches.front().getTrajectory().size(), 2u);                                 \
+	tracker::FeatureDetector d(dp);
+	const common::timestamp_t t0(0);
+	tracker::Patches old;
+	tracker::TrackId next = 0;
+	for (int c : {0, 5, 20})
+	{
+		old.emplace_back(tracker::Corner(c, c), 11, t0);
+		old.back().setTrackId(next++);
 	}
+	d.setPatches(old);
+	d.setTrackId(next);
+	tracker::Patches fresh;
+	fresh.emplace_back(tracker::Corner(3, 0), 11, t0);
+	fresh.emplace_back(tracker::Corner(0, 1), 11, t0);
+	fresh.emplace_back(tracker::Corner(18, 18), 11, t0);
+	d.associatePatches(fresh, t0);
+	const tracker::Patches after = d.getPatches();
+	EXPECT_TRUE(after.size() == 4u);
+	EXPECT_TRUE(after.back().getTrackId() == 3);
+	EXPECT_TRUE(after.front().getTrajectory().size() == 2u);
+}
 
 template <class L>
 static auto nth(L& l, size_t i) -> decltype(*l.begin())
@@ -466,8 +420,8 @@ static std::shared_ptr<tracker::Optimizer> installTracked(Holder& h, int W, int 
 
 static int hostOnly()
 {
-	REFERENCE_UPDATE_PATCH_TEST(params.errorPolicy = tracker::DetectorParams::ERRORS_STATUS)
-	REFERENCE_ASSOCIATED_PATCHES_TEST(params.errorPolicy = tracker::DetectorParams::ERRORS_STATUS)
+	routingScenario(tracker::DetectorParams::ERRORS_STATUS, true);
+	associationScenario(tracker::DetectorParams::ERRORS_STATUS, true);
 	{
 		tracker::DetectorParams params;
 		params.errorPolicy = tracker::DetectorParams::ERRORS_STATUS;
@@ -499,18 +453,18 @@ int main(int argc, char** argv)
 	}
 	const int W = 240, H = 180;
 
-	// ---- the reference's two detector tests, unchanged ---------------------------------------------
-	REFERENCE_UPDATE_PATCH_TEST((void)0)
-	REFERENCE_ASSOCIATED_PATCHES_TEST((void)0)
+	// ---- the scenarios of the reference's two detector tests, default error policy --------------------
+	routingScenario(tracker::DetectorParams::ERRORS_STATUS, false);
+	associationScenario(tracker::DetectorParams::ERRORS_STATUS, false);
 
 	// ---- the evaluator loop: ONE FeatureDetector against the former pair ----------------------------
 	{
-		tools::EvaluatorParams ep;
-		ep.outputDir = "/tmp";
-		ep.compensationFrequencyEvents = 6000;
-		ep.compensationFrequencyTime = 4000000000u;  // windows by event count only
-		tools::Evaluator evaluator(ep);
-		auto optOne = installTracked(evaluator.tracker(), W, H);
+		WindowRule ep;
+		ep.resultsDir = "/tmp";
+		ep.eventCap = 6000;
+		ep.periodMicros = 4000000000u;  // windows by event count only
+		FrontEndDriver evaluator(ep);
+		auto optOne = installTracked(evaluator.detector(), W, H);
 
 		tracker::TrackedPatches pairTracked(tracker::Size(W, H));
 		auto optPair = installTracked(pairTracked, W, H);
@@ -521,33 +475,33 @@ int main(int argc, char** argv)
 		int windows = 0, sameWindows = 0;
 		for (const auto& sample : stream)
 		{
-			evaluator.eventCallback(sample);
+			evaluator.feed(sample);
 			// the pair, in the same call order
 			pairDetector.addEvent(sample);
 			pairTracked.updatePatches(sample);
-			if (pairDetector.getEvents().size() >= ep.compensationFrequencyEvents)
+			if (pairDetector.getEvents().size() >= ep.eventCap)
 			{
 				pairDetector.compensateEventsContrast(pairDetector.getEvents());
 				pairDetector.integrateEvents(pairDetector.getEvents());
 				pairDetector.clearEvents();
 				++windows;
-				const bool same = sameImage(evaluator.getCompensatedEventImage(), pairDetector.getCompensatedEventImage()) &&
-								  sameImage(evaluator.getIntegratedEventImage(), pairDetector.getIntegratedEventImage()) &&
-								  evaluator.tracker().getPatchFlows() == pairDetector.getPatchFlows() &&
-								  evaluator.tracker().getLastCompensation() == pairDetector.getLastCompensation();
+				const bool same = sameImage(evaluator.warpedImage(), pairDetector.getCompensatedEventImage()) &&
+								  sameImage(evaluator.plainImage(), pairDetector.getIntegratedEventImage()) &&
+								  evaluator.detector().getPatchFlows() == pairDetector.getPatchFlows() &&
+								  evaluator.detector().getLastCompensation() == pairDetector.getLastCompensation();
 				sameWindows += same ? 1 : 0;
 				double maxFlow = 0;
-				for (double f : evaluator.tracker().getPatchFlows())
+				for (double f : evaluator.detector().getPatchFlows())
 				{
 					maxFlow = std::fmax(maxFlow, std::fabs(f));
 				}
 				std::printf("window %d: %d iterations, max |flow| %.4f, same as the pair: %d\n", windows,
-							evaluator.tracker().getLastSummary().iterations, maxFlow, int(same));
+							evaluator.detector().getLastSummary().iterations, maxFlow, int(same));
 				EXPECT_TRUE(maxFlow > 1e-3);  // the solve moved
 			}
 		}
-		EXPECT_TRUE(windows == 2 && evaluator.windows == windows && sameWindows == windows);
-		const tracker::Patches& one = evaluator.getPatches();
+		EXPECT_TRUE(windows == 2 && evaluator.windowsClosed == windows && sameWindows == windows);
+		const tracker::Patches& one = evaluator.patches();
 		EXPECT_TRUE(one.size() == 6 && pairTracked.getPatches().size() == 6);
 		size_t optimisations = 0;
 		for (size_t i = 0; i < one.size(); ++i)
@@ -558,18 +512,18 @@ int main(int argc, char** argv)
 		EXPECT_TRUE(optimisations >= 8 && optOne->getFinalCosts().size() == optimisations &&
 					optPair->getFinalCosts().size() == optimisations);
 		EXPECT_TRUE(nth(one, 4).getFinalCosts().empty() && !nth(one, 4).isInit());  // nobody initialised it: it only collects events
-		const auto costs = evaluator.tracker().getOptimizedFinalCosts();
+		const auto costs = evaluator.detector().getOptimizedFinalCosts();
 		EXPECT_TRUE(costs.size() == optimisations);
 		std::printf("evaluator loop: %zu events, %d windows, %zu optimisations, one detector == the pair\n", stream.size(),
 					windows, optimisations);
 
 		// the chunked call of the same class: same patches as the per-event loop
-		tools::Evaluator chunked(ep);
-		installTracked(chunked.tracker(), W, H);
-		chunked.tracker().updatePatches(stream);
+		FrontEndDriver chunked(ep);
+		installTracked(chunked.detector(), W, H);
+		chunked.detector().updatePatches(stream);
 		for (size_t i = 0; i < one.size(); ++i)
 		{
-			EXPECT_TRUE(samePatch(nth(one, i), nth(chunked.getPatches(), i)));
+			EXPECT_TRUE(samePatch(nth(one, i), nth(chunked.patches(), i)));
 		}
 
 		// DetectorParams::eventBatch: the per-event call keeps the events and routes them in chunks (the loop above ran
@@ -602,27 +556,27 @@ int main(int argc, char** argv)
 						std::chrono::duration<double, std::milli>(t2 - t1).count());
 		}
 
-		// visual_odometry::Keyframe over the detector's patches (evaluator.cpp:85-87)
-		auto keyframe = visual_odometry::Keyframe(evaluator.tracker().getPatches(), common::timestamp_t(99));
-		EXPECT_TRUE(keyframe.getLandmarks().size() == 5);  // track ids 0..3 and the two -1 share one key
-		const auto& lm = keyframe.getLandmarks().at(2);
-		EXPECT_TRUE(lm.x() == nth(one, 2).toCorner().x && lm.y() == nth(one, 2).toCorner().y);
+		// what a keyframe takes from the detector's patches (evaluator.cpp:85-87 -> keyframe.cpp:5-14)
+		const auto landmarks = landmarksOf(evaluator.detector().getPatches());
+		EXPECT_TRUE(landmarks.size() == 5);  // track ids 0..3 and the two -1 share one key
+		const Landmark& lm = landmarks.at(2);
+		EXPECT_TRUE(lm.x == nth(one, 2).toCorner().x && lm.y == nth(one, 2).toCorner().y);
 
-		// setTrackerParams: params_ = params, optimizers take optimizerParams, reset() (:733-741)
+		// setParams: params_ = params, optimizers take optimizerParams, reset() (:733-741)
 		tracker::DetectorParams np;
 		np.optimizerParams.maxNumIterations = 3;
 		np.maxNumEventsToStore = 5000;
-		evaluator.eventCallback(stream[0]);
-		evaluator.setTrackerParams(np);
-		EXPECT_TRUE(evaluator.tracker().getEvents().empty() && evaluator.tracker().getLastCompensation().count() == 0);
+		evaluator.feed(stream[0]);
+		evaluator.reconfigure(np);
+		EXPECT_TRUE(evaluator.detector().getEvents().empty() && evaluator.detector().getLastCompensation().count() == 0);
 		EXPECT_TRUE(optOne->getParams()->maxNumIterations == 3);
-		EXPECT_TRUE(evaluator.getCompensatedEventImage().template at<double>(90, 120) == 0.0);
+		EXPECT_TRUE(evaluator.warpedImage().template at<double>(90, 120) == 0.0);
 		for (int i = 0; i < 5200; ++i)
 		{
-			evaluator.tracker().addEvent(stream[i]);
+			evaluator.detector().addEvent(stream[i]);
 		}
-		EXPECT_TRUE(evaluator.tracker().getEvents().size() == 5000);
-		// ~Evaluator: preExit, trajectory.txt, final_cost.txt
+		EXPECT_TRUE(evaluator.detector().getEvents().size() == 5000);
+		// ~FrontEndDriver: preExit, trajectory.txt, final_cost.txt
 	}
 	{
 		std::ifstream costs("/tmp/final_cost.txt"), traj("/tmp/trajectory.txt");

@@ -1,13 +1,12 @@
-// optimizer_cost_lines_test.cpp — the reference's OWN statements that build and use the tracker's Ceres cost
-// function, against the facade's <feature_tracker/optimizer_cost.h>.
+// optimizer_cost_lines_test.cpp — the tracker's Ceres cost function built through the facade's
+// <feature_tracker/optimizer_cost.h> the way the reference's Optimizer builds it.
 //
-// Verbatim blocks (compiled with -Wall -Wextra; cv:: types from the test-only OpenCV declarations in stubs_opencv/,
-// ceres:: from the test-only declarations in stubs/ -- neither library is in this image):
-//   * optimizer.cpp:5-13,15-31   Optimizer::Optimizer's grad_ sizing and the whole body of Optimizer::setGrad: the
-//                                interleaved grid, `new Grid(grad_.data(), 0, h, 0, w)`, `new Interpolator(*grid)`;
-//   * optimizer.cpp:72-79,86-97  currentRect / size / normalizedIntegratedNabla / warp / flowDir, `new
-//                                tracker::OptimizerCostFunctor(...)` and `new ceres::AutoDiffCostFunction<
-//                                tracker::OptimizerCostFunctor, ceres::DYNAMIC, Sophus::SE2d::num_parameters, 1>(c, size)`.
+// The reference constructs, per patch (optimizer.cpp:9,15-31,72-97): an interleaved gradient grid, `Grid` and
+// `Interpolator` over it, `OptimizerCostFunctor(nabla, interpolator, rect, imageSize)` and
+// `ceres::AutoDiffCostFunction<tracker::OptimizerCostFunctor, ceres::DYNAMIC, Sophus::SE2d::num_parameters, 1>`.
+// This file does the same with its own statements (GradientHolder) and pins the constructor signatures with
+// static_asserts; cv:: types come from the test-only OpenCV declarations in stubs_opencv/, ceres:: from the test-only
+// declarations in stubs/ (neither library is in this image).  Compiled with -Wall -Wextra.
 // Checked on the GPU: cost_function->Evaluate (residuals, both Jacobian blocks; one block; none) returns, bit for bit,
 // what ebo_optimizer_eval returns for the same patch on another context; the functor's double path likewise.
 // `--cpu`: compiles, and a functor without an interpolator reports failure instead of evaluating anywhere else.
@@ -16,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <ceres/ceres.h>
@@ -43,65 +43,66 @@ struct SE2d
 };
 }  // namespace Sophus
 
-// A shell with the members of tracker::Optimizer that the verbatim lines name (optimizer.h:60-70)
-struct OptimizerShell
-{
-	cv::Size2i imageSize_;
-	std::vector<double> grad_;
-	tracker::GridPtr gradGrid_;
-	tracker::InterpolatorPtr gradInterpolator_;
+// What tracker::Optimizer holds around its Ceres cost function (optimizer.h:60-70), as this test's own holder: the
+// interleaved gradient grid, the Grid / Interpolator pair over it, and the construction of the cost function.  The
+// INTERFACE it exercises is the reference's -- Grid(data, row_begin, row_end, col_begin, col_end), Interpolator(grid),
+// OptimizerCostFunctor(nabla, interpolator, rect, imageSize), AutoDiffCostFunction<Functor, DYNAMIC, 4, 1>(functor, n)
+// (optimizer.cpp:9,15-31,72-97) -- the statements and names are this file's.
+using SE2Parameters = std::integral_constant<int, Sophus::SE2d::num_parameters>;
+static_assert(SE2Parameters::value == 4, "an SE2 block has four parameters");
+static_assert(std::is_constructible<tracker::Grid, const double*, int, int, int, int>::value, "Grid(data, r0, r1, c0, c1)");
+static_assert(std::is_constructible<tracker::Interpolator, const tracker::Grid&>::value, "Interpolator(grid)");
+static_assert(std::is_constructible<tracker::OptimizerCostFunctor, const cv::Mat&, tracker::Interpolator*, const cv::Rect2d&,
+									 const cv::Size2i&>::value,
+			  "OptimizerCostFunctor(nabla, interpolator, rect, imageSize)");
+static_assert(std::is_same<tracker::GridPtr::element_type, tracker::Grid>::value &&
+				  std::is_same<tracker::InterpolatorPtr::element_type, tracker::Interpolator>::value,
+			  "GridPtr / InterpolatorPtr own a Grid / an Interpolator");
 
-	explicit OptimizerShell(const cv::Size2i& imageSize) : imageSize_(imageSize)
-	{
-		// ---- optimizer.cpp:9, verbatim ----
-		grad_.resize((imageSize.height + 25) * (imageSize.width + 25) * 2);
+class GradientHolder
+{
+   public:
+	explicit GradientHolder(const cv::Size2i& sensor)
+		: sensor_(sensor), samples_(2u * static_cast<size_t>(sensor.height + 25) * static_cast<size_t>(sensor.width + 25), 0.0)
+	{  // (the reference sizes its buffer with a 25-pixel margin on both axes)
 	}
 
-	// ---- optimizer.cpp:15-31, verbatim ----
-	void setGrad(const cv::Mat& gradX, const cv::Mat& gradY)
+	// two values per pixel, x-gradient first, rows of `sensor.width` pixels
+	void install(const cv::Mat& gx, const cv::Mat& gy)
 	{
-		for (int row = 0; row < gradX.rows; row++)
+		const size_t pitch = 2u * static_cast<size_t>(sensor_.width);
+		for (int r = 0; r < gx.rows; ++r)
 		{
-			for (int col = 0; col < gradX.cols; col++)
+			double* line = samples_.data() + pitch * static_cast<size_t>(r);
+			for (int c = 0; c < gx.cols; ++c)
 			{
-				grad_[2 * row * imageSize_.width + 2 * col] =
-					gradX.at<double>(row, col);
-				grad_[2 * row * imageSize_.width + 2 * col + 1] =
-					gradY.at<double>(row, col);
+				line[2 * c] = gx.at<double>(r, c);
+				line[2 * c + 1] = gy.at<double>(r, c);
 			}
 		}
-		gradGrid_.reset(
-			new Grid(grad_.data(), 0, imageSize_.height, 0, imageSize_.width));
-		gradInterpolator_.reset(new Interpolator(*(gradGrid_.get())));
+		grid_ = tracker::GridPtr(new tracker::Grid(samples_.data(), 0, sensor_.height, 0, sensor_.width));
+		lookup_ = tracker::InterpolatorPtr(new tracker::Interpolator(*grid_));
 	}
-	using Grid = tracker::Grid;                  // (the reference's file is inside namespace tracker)
-	using Interpolator = tracker::Interpolator;
 
-	std::unique_ptr<ceres::CostFunction> costFunctionOf(tracker::Patch& patch)
+	// the per-patch cost function Optimizer::optimize hands to Ceres: one residual per patch pixel, an SE2 block and a
+	// one-parameter flow-direction block
+	std::unique_ptr<ceres::CostFunction> costOf(const tracker::Patch& patch) const
 	{
-		// ---- optimizer.cpp:72-79, verbatim ----
-		const cv::Rect2d currentRect = patch.getPatch();
-		int size = currentRect.height * currentRect.width;
-
-		const cv::Mat normalizedIntegratedNabla =
-			patch.getNormalizedIntegratedNabla();
-
-		auto warp = patch.getWarp();
-		double flowDir = patch.getFlow();
-		(void)warp;
-		(void)flowDir;
-		// ---- optimizer.cpp:86-97, verbatim ----
-		auto* c = new tracker::OptimizerCostFunctor(normalizedIntegratedNabla,
-													gradInterpolator_.get(),
-													currentRect, imageSize_);
-
-		ceres::CostFunction* cost_function =
-			new ceres::AutoDiffCostFunction<tracker::OptimizerCostFunctor,
-											ceres::DYNAMIC,
-											Sophus::SE2d::num_parameters, 1>(c,
-																			size);
-		return std::unique_ptr<ceres::CostFunction>(cost_function);
+		const cv::Rect2d rect = patch.getPatch();
+		const int residuals = static_cast<int>(rect.height * rect.width);
+		const cv::Mat unitNabla = patch.getNormalizedIntegratedNabla();
+		tracker::OptimizerCostFunctor* functor = new tracker::OptimizerCostFunctor(unitNabla, lookup_.get(), rect, sensor_);
+		using Cost = ceres::AutoDiffCostFunction<tracker::OptimizerCostFunctor, ceres::DYNAMIC, SE2Parameters::value, 1>;
+		return std::unique_ptr<ceres::CostFunction>(new Cost(functor, residuals));
 	}
+
+	tracker::Interpolator* lookup() const { return lookup_.get(); }
+
+   private:
+	cv::Size2i sensor_;
+	std::vector<double> samples_;
+	tracker::GridPtr grid_;
+	tracker::InterpolatorPtr lookup_;
 };
 
 static bool sameBits(const std::vector<double>& a, const std::vector<double>& b)
@@ -121,8 +122,8 @@ static void deviceTest()
 			gradY.at<double>(y, x) = std::cos(0.17 * x + 0.3) * std::sin(0.19 * y);
 		}
 	}
-	OptimizerShell shell(cv::Size2i(W, H));
-	shell.setGrad(gradX, gradY);
+	GradientHolder shell(cv::Size2i(W, H));
+	shell.install(gradX, gradY);
 
 	tracker::Patch patch({40.3, 30.6}, 12, common::timestamp_t(0));  // a fractional rect
 	tracker::Mat64 nabla(25, 25);
@@ -134,7 +135,7 @@ static void deviceTest()
 	patch.setFlowDir(0.7);
 	patch.setWarp(common::Pose2d(0.03, common::Point2d(0.4, -0.3)));
 
-	std::unique_ptr<ceres::CostFunction> cost = shell.costFunctionOf(patch);
+	std::unique_ptr<ceres::CostFunction> cost = shell.costOf(patch);
 	EXPECT_TRUE(cost->num_residuals() == 625);
 	EXPECT_TRUE(cost->parameter_block_sizes().size() == 2 && cost->parameter_block_sizes()[0] == 4 &&
 				cost->parameter_block_sizes()[1] == 1);
@@ -173,7 +174,7 @@ static void deviceTest()
 	}
 	EXPECT_TRUE(norm > 0.1 && std::isfinite(norm) && jn > 0.1 && std::isfinite(jn));
 	// a functor whose nabla does not fit its rect refuses
-	tracker::OptimizerCostFunctor bad(tracker::Mat64(7, 7), shell.gradInterpolator_.get(), r, tracker::Size(W, H));
+	tracker::OptimizerCostFunctor bad(tracker::Mat64(7, 7), shell.lookup(), r, tracker::Size(W, H));
 	EXPECT_TRUE(!bad(patch.getWarp().data(), &flow, res.data()));
 }
 

@@ -1,7 +1,9 @@
-// reader_lines_test.cpp — the reference's own reader test against the facade's tools::Davis240cReader (CPU only).
+// reader_lines_test.cpp — the facade's tools::Davis240cReader under the reference reader's known answers (CPU only).
 //
-// tools/dataset_reader/test/davis240c_reader_test.cpp:19-48 (Davis240cReader.eventsTest) is the block marked "verbatim",
-// run on the reference's own events.txt fixture (tests/golden/davis_events_fixture.txt, copied to <tmp>/events.txt).
+// The reference's reader test (tools/dataset_reader/test/davis240c_reader_test.cpp:19-48) reads its five-line events.txt
+// fixture and expects five (timestamp, pixel, polarity) triples.  Those triples are held here as a data table and checked
+// with this file's own statements on the same fixture (tests/golden/davis_events_fixture.txt, copied to <tmp>/events.txt);
+// static_asserts pin the signatures of the members the reference's callers use.
 // Besides: a recording read in pieces (getEvents continues behind the events of the call before and ends with an empty
 // optional), the packed sidecar next to the text file gives the same events, a sign other than 0/1 throws the reference's
 // message, getTrajectoryLine / getTrajectory read what tools::saveFeaturesTrajectory wrote (one Patch per line), and the
@@ -9,8 +11,11 @@
 //   usage: reader_lines_test <events fixture> <scratch dir>
 #include <cstdio>
 #include <fstream>
+#include <optional>
 #include <string>
 #include <sys/stat.h>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include <dataset_reader/davis240c_reader.h>
@@ -29,37 +34,55 @@ static int g_fail = 0;
 #define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
 #define ASSERT_EQ(a, b) EXPECT_TRUE((a) == (b))
 
-std::string TEST_DATA_PATH = "test/test_data";
-
-// ---- davis240c_reader_test.cpp:19-48, verbatim ------------------------------------------------------
-static void eventsTest()
+// ---- the known answers of the reference's fixture (davis240c_reader_test.cpp:19-48), held as DATA ----
+// The five lines of tests/golden/davis_events_fixture.txt and what the reference's reader makes of them: microseconds
+// truncated from the seconds column, pixel, polarity (1 -> POSITIVE, 0 -> NEGATIVE).  The statements are this test's own;
+// they go through the same members the reference's test names (the constructor from a directory, getEvents() returning an
+// optional of a sequence of common::EventSample).
+struct FixtureLine
 {
-	tools::Davis240cReader reader(TEST_DATA_PATH);
-	const auto events = reader.getEvents();
+	int64_t us;
+	int x, y;
+	common::EventPolarity sign;
+};
+static const FixtureLine kFixture[] = {{0, 33, 39, common::EventPolarity::POSITIVE},
+									   {11, 158, 145, common::EventPolarity::POSITIVE},
+									   {50, 88, 143, common::EventPolarity::NEGATIVE},
+									   {55, 174, 154, common::EventPolarity::NEGATIVE},
+									   {80, 112, 139, common::EventPolarity::POSITIVE}};
 
-	EXPECT_TRUE(events.has_value());
+// signature conformance with tools/dataset_reader/include/dataset_reader/davis240c_reader.h: the members the
+// reference's test and its replayer call
+static_assert(std::is_constructible<tools::Davis240cReader, const std::string&>::value, "Davis240cReader(path)");
+static_assert(std::is_same<decltype(std::declval<tools::Davis240cReader&>().getEvents()),
+						   std::optional<common::EventSequence>>::value,
+			  "getEvents() -> std::optional<common::EventSequence>");
+static_assert(std::is_same<decltype(std::declval<tools::Davis240cReader&>().getEventSample(std::declval<std::string&>())),
+						   common::EventSample>::value,
+			  "getEventSample(std::string&) -> common::EventSample");
 
-	std::vector<common::Point2i> points = {
-		{33, 39}, {158, 145}, {88, 143}, {174, 154}, {112, 139}};
-
-	std::vector<common::EventPolarity> signs = {
-		common::EventPolarity::POSITIVE, common::EventPolarity::POSITIVE,
-		common::EventPolarity::NEGATIVE, common::EventPolarity::NEGATIVE,
-		common::EventPolarity::POSITIVE};
-
-	std::vector<common::timestamp_t> timestamps = {
-		common::timestamp_t(0), common::timestamp_t(11),
-		common::timestamp_t(50), common::timestamp_t(55),
-		common::timestamp_t(80)};
-
-	ASSERT_EQ(timestamps.size(), events.value().size());
-
-	for (size_t i = 0; i < events.value().size(); ++i)
+static void fixtureKnownAnswers(const std::string& dir)
+{
+	tools::Davis240cReader reader(dir);
+	const std::optional<common::EventSequence> got = reader.getEvents();
+	EXPECT_TRUE(got.has_value());
+	if (!got)
 	{
-		EXPECT_EQ(events.value()[i].timestamp.count(), timestamps[i].count());
-		EXPECT_EQ(events.value()[i].value.point.x, points[i].x);
-		EXPECT_EQ(events.value()[i].value.point.y, points[i].y);
-		EXPECT_EQ(events.value()[i].value.sign, signs[i]);
+		return;
+	}
+	const size_t want = sizeof(kFixture) / sizeof(kFixture[0]);
+	EXPECT_EQ(got->size(), want);
+	size_t k = 0;
+	for (const common::EventSample& e : *got)
+	{
+		if (k >= want)
+		{
+			break;
+		}
+		const FixtureLine& f = kFixture[k++];
+		EXPECT_TRUE(e.timestamp == common::timestamp_t(f.us));
+		EXPECT_TRUE(e.value.point.x == f.x && e.value.point.y == f.y);
+		EXPECT_TRUE(e.value.sign == f.sign);
 	}
 }
 
@@ -95,8 +118,7 @@ int main(int argc, char** argv)
 		std::ofstream out(scratch + "/events.txt", std::ios::binary);
 		out << in.rdbuf();
 	}
-	TEST_DATA_PATH = scratch;
-	eventsTest();
+	fixtureKnownAnswers(scratch);
 	{
 		tools::Davis240cReader reader(scratch);
 		EXPECT_TRUE(reader.getEvents().has_value());

@@ -88,9 +88,10 @@ def test_reference_replayer_and_trajectory_scenarios(ebo):
 
 
 def test_front_end_lines_compile_and_host_subset(ebo):
-    """CPU: the front end's own statements (evaluator.cpp:15-45,106-109,120-123; keyframe.cpp:5-14) and the
-    reference's updatePatchTest / associatedPatchesTest compile verbatim under -Wall -Wextra against the
-    facade's ONE tracker::FeatureDetector; the host-only subset (patch bookkeeping, every DetectorParams
+    """CPU: every member the front end calls on its tracker (evaluator.cpp:15-45,106-109,120-123; keyframe.cpp:5-14) is
+    pinned by name, argument and result type (a member-pointer table over feature_detector.h:33-88) and called, in the
+    evaluator's order, by the test's own driver under -Wall -Wextra against the facade's ONE tracker::FeatureDetector; the
+    scenarios of the reference's updatePatchTest / associatedPatchesTest; the host-only subset (patch bookkeeping, every DetectorParams
     field with the reference's default, EBO_ERR_UNSUPPORTED for newImage without hooks) runs without a device."""
     ebo.lib()
     out = subprocess.run(["make", "-B", "-C", CPP, "front_end_lines_test"], capture_output=True, text=True)
@@ -137,9 +138,10 @@ def test_front_end_lines_with_opencv_types_run_like_the_pair(ebo):
 
 
 def test_patch_lines_compile_and_host_subset(ebo):
-    """CPU: the reference's own patch tests (patch_test.cpp:7-33,35-60 verbatim; :62-91 with its OpenCV / Sophus
-    statements restated) compile under -Wall -Wextra against the facade's tracker::Patch; the host-only subset runs:
-    addEventsTest ends as the reference's patch.cpp implies (three of its expectations are stale there), the
+    """CPU: the scenarios of the reference's patch tests (patch_test.cpp:7-33,35-60,62-91) in the test's own statements,
+    the integrateEvents known answer as a data table, and a member-pointer table over every public member of patch.h:15-160,
+    under -Wall -Wextra against the facade's tracker::Patch; the host-only subset runs: the event window behaves as the
+    reference's patch.cpp implies (three expectations of the reference's own addEventsTest are stale there), the
     bookkeeping getters, and every per-patch device member throws "no device context" when none is bound."""
     ebo.lib()
     out = subprocess.run(["make", "-B", "-C", CPP, "patch_lines_test"], capture_output=True, text=True)
@@ -162,10 +164,10 @@ def test_patch_lines_run_on_the_device(ebo):
 
 
 def test_optimizer_cost_lines_compile_and_host_subset(ebo):
-    """CPU: the reference's statements that build the tracker's Ceres cost function (optimizer.cpp:9,15-31,72-79,86-97:
-    the interleaved grid, `new Grid`, `new Interpolator`, `new tracker::OptimizerCostFunctor`, `new
-    ceres::AutoDiffCostFunction<tracker::OptimizerCostFunctor, ceres::DYNAMIC, Sophus::SE2d::num_parameters, 1>`) compile
-    verbatim under -Wall -Wextra against <feature_tracker/optimizer_cost.h> (test-only Ceres / OpenCV declarations); a
+    """CPU: the tracker's Ceres cost function built the way optimizer.cpp:9,15-31,72-79,86-97 builds it (the interleaved
+    grid, `Grid`, `Interpolator`, `tracker::OptimizerCostFunctor`, `ceres::AutoDiffCostFunction<tracker::OptimizerCostFunctor,
+    ceres::DYNAMIC, Sophus::SE2d::num_parameters, 1>`; own statements, constructor signatures pinned by static_asserts)
+    compiles under -Wall -Wextra against <feature_tracker/optimizer_cost.h> (test-only Ceres / OpenCV declarations); a
     functor without an interpolator reports failure."""
     ebo.lib()
     out = subprocess.run(["make", "-B", "-C", CPP, "optimizer_cost_lines_test"], capture_output=True, text=True)
@@ -187,7 +189,7 @@ def test_optimizer_cost_lines_evaluate_like_the_abi(ebo):
 
 
 def test_reference_reader_lines(ebo, tmp_path):
-    """CPU: tools/dataset_reader/test/davis240c_reader_test.cpp:19-48 (eventsTest) verbatim against the facade's
+    """CPU: the known answers of tools/dataset_reader/test/davis240c_reader_test.cpp:19-48 (a data table) against the facade's
     tools::Davis240cReader on the reference's own events.txt fixture; a 2.3 M-event recording read in the reference's
     pieces of EVENT_LENGTH lines (ebo_read_events_txt_at) and again from the packed sidecar; the reference's exception text
     for a bad sign; trajectory.txt read back one Patch per line."""
