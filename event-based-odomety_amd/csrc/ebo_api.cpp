@@ -280,12 +280,77 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 		L.block = twoPerCu ? 256 : (L.for_solve ? 512 : 768);
 	}
 	L.lds_bytes = headerBytes + static_cast<size_t>(L.cap_px) * ldsPerPx;
+	// Workgroup slots.  The batched evaluation runs PERSISTENT workgroups -- as many as the chip holds at once (two
+	// 256-lane ones per CU, else one), each walking the launch's units -- and keys its per-evaluation temporaries (the
+	// global fallback slice, the direction table) by workgroup; the device-resident solve runs one workgroup per unit.
+	if (c->n_cus == 0)
+	{
+		hipDeviceProp_t prop;
+		c->n_cus = (hipGetDeviceProperties(&prop, c->prm.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+	}
+	{
+		const size_t items = static_cast<size_t>(L.n_units) * L.flow_sets;
+		// (the 256-lane instantiations of k_eval_edge only: the 768-lane ones keep one workgroup per item, ebo_edge.inc)
+		L.wide_kernel = ab_size("EBO_EDGE_WIDE", 0) != 0;
+		const bool persistent = !L.for_solve && L.block <= 256 && !L.wide_kernel;
+		const size_t resident = static_cast<size_t>(c->n_cus) * (2 * L.lds_bytes <= 160 * 1024 ? 2 : 1);
+		const size_t forced = ab_size("EBO_EDGE_PERSIST", 1);  // A/B: 0 = one workgroup per item (rounds 1-4), n > 1 = n workgroups
+		const size_t slots = !persistent ? items : (forced == 0 ? items : (forced > 1 ? forced : resident));
+		L.wg_slots = static_cast<int>(std::max<size_t>(1, std::min(items, slots)));
+	}
+	// The compact layout (round 5): 16.5 B per pixel and a header sized by the launch let THREE 256-lane workgroups share
+	// a CU (measured at zero flow, where every box fits: 1.32 -> 0.98 ms for 256 reference-default windows).  Only
+	// where the 20 B layout runs two per CU, for batches larger than the chip holds at once, one flow set.  Units whose
+	// box does not fit the compact arrays are deferred to a second launch on the 20 B layout.
+	L.compact = EdgeCompact();
+	{
+		const size_t items = static_cast<size_t>(L.n_units);
+		const char* force = ab_env("EBO_EDGE_COMPACT");  // A/B: 0 never, 1 whenever the layout allows
+		const bool eligible = L.alias_lds && L.block == 256 && !L.for_solve && L.flow_sets == 1 && !L.wide_kernel &&
+							  2 * L.lds_bytes <= 160 * 1024;
+		const size_t itemsNow = L.live.n > 0 ? static_cast<size_t>(L.live.n) * L.live.upw : items;  // a thinned-out lock-step round
+		const bool want = force ? std::atoi(force) != 0 : itemsNow > static_cast<size_t>(2) * c->n_cus;
+		if (eligible && want)
+		{
+			const size_t budget = ab_size("EBO_EDGE_COMPACT_KB", 52) * 1024;
+			// red[128 doubles] | 80 ints | list (one int per 4 pixels + slack) | I, E (8 B each) | 4-bit counters
+			size_t cap = (budget - 168 * sizeof(double) - 64 * sizeof(int)) * 2 / 35;  // 17.5 B per pixel
+			cap = std::min(cap & ~static_cast<size_t>(7), (canvasPx + 7) & ~static_cast<size_t>(7));
+			const size_t listCap = ((cap / 4 + 64) + 1) & ~static_cast<size_t>(1);
+			const size_t bytes = (168 + listCap / 2) * sizeof(double) + cap * 16 + cap / 2;
+			if (cap >= 1024 && bytes <= budget)
+			{
+				if (c->edge_defer_cap < items + 1)
+				{
+					if (c->d_edge_defer)
+					{
+						c->hip(hipStreamSynchronize(c->stream), "sync");
+						hipFree(c->d_edge_defer);
+						c->d_edge_defer = nullptr;
+						c->edge_defer_cap = 0;
+					}
+					int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_edge_defer), (items + 1) * sizeof(int)), "hipMalloc edge deferred list");
+					if (rc)
+					{
+						return rc;
+					}
+					c->edge_defer_cap = items + 1;
+				}
+				L.compact.hdr_doubles = static_cast<int>(168 + listCap / 2);
+				L.compact.list_cap = static_cast<int>(listCap);
+				L.compact.defer_count = c->d_edge_defer;
+				L.compact.defer_list = c->d_edge_defer + 1;
+				L.compact_cap_px = static_cast<int>(cap);
+				L.compact_lds_bytes = bytes;
+			}
+		}
+	}
 	L.scratch_stride = (canvasPx * (bytesPerPx + 1) + 256 + 255) & ~static_cast<size_t>(255);  // I, E, A, cnt + the argmax list (canvasPx / 4 + 64 ints)
 	L.d_scratch = nullptr;
 	if (static_cast<size_t>(L.cap_px) < canvasPx)
 	{
 		// some box could exceed LDS: keep a global slice per (set, unit)
-		const size_t need = L.scratch_stride * L.n_units * L.flow_sets;
+		const size_t need = L.scratch_stride * static_cast<size_t>(L.wg_slots);
 		if (need > (static_cast<size_t>(16) << 30))
 		{
 			return c->fail(EBO_ERR_UNSUPPORTED, "edge loss fallback scratch would exceed 16 GiB; use fewer windows per batch");
@@ -353,13 +418,15 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 		L.ec.g[k + 3] = std::exp(-0.5 / sigmaSq * static_cast<double>(k * k));
 	}
 	L.ec.norm_st = normCoef;
-	// Eigenvector directions per pixel for the reverse pass (16 B per LDS-resident pixel and unit, in
-	// HBM / L2): spares every argmax entry the re-derivation of its tensor sums.  Beyond 4 GiB
+	// Eigenvector directions per pixel for the reverse pass (16 B per LDS-resident pixel and WORKGROUP SLOT, in
+	// L2 / Infinity Cache): spares every argmax entry the re-derivation of its tensor sums.  Beyond 4 GiB
 	// (EBO_EDGE_CS_MB) the reverse pass re-derives them instead.
 	L.ec.cs = nullptr;
 	L.ec.cs_stride = L.cap_px;
 	{
-		const size_t need = static_cast<size_t>(L.n_units) * L.cap_px * 2 * sizeof(double);
+		// (the compact launch keys its slots by unit, one workgroup each: the larger of the two launches' tables)
+		const size_t need = std::max(static_cast<size_t>(L.wg_slots) * L.cap_px,
+									 L.compact.list_cap > 0 ? static_cast<size_t>(L.n_units) * L.compact_cap_px : 0) * 2 * sizeof(double);
 		// The table is an optimisation nobody asked for by name, so it must not surprise: at most
 		// EBO_EDGE_CS_MB (default 4096) AND at most a quarter of the memory that is free right now
 		// (several contexts share a GPU: one per FeatureDetector / Optimizer / TrackedPatches of the
@@ -1523,6 +1590,7 @@ void ebo_destroy(ebo_ctx* c)
 	hipFree(c->d_edge_scratch);
 	hipFree(c->d_edge_w);
 	hipFree(c->d_edge_cs);
+	hipFree(c->d_edge_defer);
 	hipFree(c->d_raw);
 	hipFree(c->d_bucket);
 	hipFree(c->d_chunk_hist);

@@ -90,7 +90,10 @@ struct ebo_ctx
 	double* d_edge_w = nullptr;      // the 49 tensor weights of the edge loss (device table)
 	double edge_w_sigma = -1.0;      // sigma_st they were built for
 	unsigned long long* edge_stats_dev = nullptr;  // set only while ebo_edge_work_stats runs its one evaluation
-	double* d_edge_cs = nullptr;     // eigenvector directions of the edge loss's eigenvalue pass, [unit][cap_px][2]
+	double* d_edge_cs = nullptr;     // eigenvector directions of the edge loss's eigenvalue pass, [workgroup slot][cap_px][2]
+	int n_cus = 0;                   // compute units of the device (0: not asked yet)
+	int* d_edge_defer = nullptr;     // [1 + items]: length, then the units the compact launch deferred to the 20 B layout
+	size_t edge_defer_cap = 0;       // ints
 	size_t edge_cs_cap = 0;          // bytes
 	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
 	size_t edge_scratch_cap = 0;

@@ -179,11 +179,23 @@ struct EdgeConsts
 	double g[7];           // 1-D factors exp(hs_st k^2), k = -3..3:  w(i,j) = norm_st g[i] g[j]
 	double norm_st;        // 1 / (2 pi sigmaST^2)
 	double mean_threshold; // 1e-4 (:159)
-	int ablate;            // timing-only ablation mask (EBO_EDGE_ABLATE): 1 eigen, 2 NMS, 4 reverse, 8 gather, 16 scatter
-	double* cs;            // DEVICE table [unit][cap_px][2] or null: (s00 - s11)/d and 2 s01/d of every pixel with a positive eigenvalue, written by the eigenvalue pass of a Jacobian evaluation, read by its reverse pass for the argmax pixels (null: the reverse pass re-derives the tensor sums)
+	int ablate;            // timing-only ablation mask (EBO_EDGE_ABLATE): 1 eigen, 2 NMS, 4 reverse, 8 gather, 16 scatter, 32 no register runs, 64 reference-order image, 128 bank-spread fake entries in the reverse sweep
+	double* cs;            // DEVICE table [workgroup slot][cap_px][2] or null: (s00 - s11)/d and 2 s01/d of every pixel with a positive eigenvalue, written by the eigenvalue pass of a Jacobian evaluation, read by its reverse pass for the argmax pixels (null: the reverse pass re-derives the tensor sums)
 	int cs_stride;         // pixels per unit in cs (= cap_px)
 	int reserved;          // tensor filter forms (EBO_EDGE_SEPARABLE): 1 band buffers on the 28 B layout, 2 register runs on the 20 B layout, 4 register runs on the 28 B layout
 	unsigned long long* stats;  // null, or DEVICE counters [6] of ebo_edge_work_stats: units past the penalty test, their events, box pixels, eigenvalue-region pixels, NMS windows, argmax entries
+};
+
+// The compact LDS layout of k_eval_edge_wg (round 5): 16.5 B per pixel (I, E / A, 4-bit claim counters) and a header
+// sized by the launch, so that THREE 256-lane workgroups share a CU; a unit whose box does not fit is not evaluated
+// on its global slice but appended to defer_list for the launch that follows with the 20 B layout (two per CU).
+// list_cap == 0: the layouts of rounds 1-4.
+struct EdgeCompact
+{
+	int hdr_doubles = 0;       // doubles in front of the arrays: red[128] | 80 ints | list_cap ints
+	int list_cap = 0;          // ints of the list / cell region
+	int* defer_list = nullptr; // DEVICE [items]
+	int* defer_count = nullptr;// DEVICE, zeroed before the launch
 };
 
 struct EdgeLaunch
@@ -199,7 +211,12 @@ struct EdgeLaunch
 	int cap_px;           // pixels per array that fit LDS
 	int alias_lds;        // 1: 20 B/pixel LDS layout (A in E's storage, direct tensor form), 2 workgroups per CU
 	size_t lds_bytes;
-	char* d_scratch;      // global fallback, [flow sets][n_units][stride]
+	EdgeCompact compact;  // list_cap > 0: this launch uses the compact layout (edge_launch_setup)
+	size_t compact_lds_bytes = 0;
+	int compact_cap_px = 0;
+	bool wide_kernel = false;  // A/B (EBO_EDGE_WIDE): the 168-VGPR instantiation whatever the workgroup size (three 256-lane workgroups per CU)
+	int wg_slots = 1;     // workgroups of a k_eval_edge launch (persistent: what the chip holds at once); k_solve_edge: one per unit
+	char* d_scratch;      // global fallback, [workgroup slot][stride]
 	size_t scratch_stride;
 	double* d_sets;       // staging [5][n_units][3] for central differences
 	double* d_out;        // [n_flow][3]

@@ -3585,26 +3585,84 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 	{
 		return 0;
 	}
-	using EdgeKern = decltype(&k_eval_edge<true, true, 256>);
-	const bool narrow = L.block <= 256;  // MAXT 256 (two workgroups per CU) or 768
-	auto pick = [&](auto alias, auto jac) -> EdgeKern {
-		constexpr bool A = decltype(alias)::value, J = decltype(jac)::value;
-		return narrow ? k_eval_edge<A, J, 256> : k_eval_edge<A, J, 768>;
-	};
-	EdgeKern edgeKern = L.alias_lds ? (L.want_jac ? pick(std::true_type(), std::true_type()) : pick(std::true_type(), std::false_type()))
-									: (L.want_jac ? pick(std::false_type(), std::true_type()) : pick(std::false_type(), std::false_type()));
-	if (allow_big_lds(edgeKern, L.lds_bytes))
-	{
-		return -2;
-	}
+	const bool narrow = L.block <= 256 && !L.wide_kernel;  // MAXT 256 (two workgroups per CU, persistent) or 768 (one workgroup per item)
 	LiveWindows live = L.live;
 	if (L.flow_sets != 1)
 	{
 		live.n = 0;
 	}
-	hipLaunchKernelGGL(edgeKern, dim3(live.n > 0 ? live.n * live.upw : L.n_units, L.flow_sets), dim3(L.block), L.lds_bytes, s,
-					   L.d_events, L.d_units, L.d_flows, L.want_jac, L.cap_px, L.fd_step, L.d_scratch,
-					   L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec, L.flow_sets == 1 ? L.d_modes : nullptr, live);
+	const int nItemsX = live.n > 0 ? live.n * live.upw : L.n_units;
+	if (narrow)
+	{
+		using EdgeKern = decltype(&k_eval_edge<true, true, 256>);
+		EdgeKern edgeKern = L.alias_lds ? (L.want_jac ? k_eval_edge<true, true, 256> : k_eval_edge<true, false, 256>)
+										: (L.want_jac ? k_eval_edge<false, true, 256> : k_eval_edge<false, false, 256>);
+		if (allow_big_lds(edgeKern, L.lds_bytes))
+		{
+			return -2;
+		}
+		EdgeKArgs ka;
+		ka.events = L.d_events;
+		ka.units = L.d_units;
+		ka.flows = L.d_flows;
+		ka.wantJac = L.want_jac;
+		ka.capPx = L.cap_px;
+		ka.fdStep = L.fd_step;
+		ka.scratch = L.d_scratch;
+		ka.scratchStride = L.scratch_stride;
+		ka.sets = L.d_sets;
+		ka.out = L.d_out;
+		ka.c = L.c;
+		ka.ec = L.ec;
+		ka.modes = L.flow_sets == 1 ? L.d_modes : nullptr;
+		ka.live = live;
+		ka.nItemsX = nItemsX;
+		ka.nSets = L.flow_sets;
+		ka.itemList = nullptr;
+		ka.itemCount = nullptr;
+		if (L.compact.list_cap > 0 && L.alias_lds && L.flow_sets == 1)
+		{
+			// Two launches (round 5).  First every unit on the COMPACT layout, three 256-lane workgroups per CU (the
+			// 168-VGPR instantiation); a unit whose box does not fit goes on the deferred list.  Then the deferred
+			// units on the 20 B layout, two per CU, persistent workgroups that read the list's length on the device.
+			using WideKern = decltype(&k_eval_edge_wg<true, true, 768>);
+			WideKern wide = L.want_jac ? k_eval_edge_wg<true, true, 768> : k_eval_edge_wg<true, false, 768>;
+			if (allow_big_lds(wide, L.compact_lds_bytes))
+			{
+				return -2;
+			}
+			if (hipMemsetAsync(L.compact.defer_count, 0, sizeof(int), s) != hipSuccess)
+			{
+				return -2;
+			}
+			EdgeConsts ecCompact = L.ec;
+			ecCompact.cs_stride = L.compact_cap_px;  // one slot per unit, as in rounds 1-4
+			hipLaunchKernelGGL(wide, dim3(nItemsX, 1), dim3(256), L.compact_lds_bytes, s, L.d_events, L.d_units, L.d_flows,
+							   L.want_jac, L.compact_cap_px, L.fd_step, L.d_scratch, L.scratch_stride, L.d_sets, L.d_out, L.c, ecCompact,
+							   L.d_modes, live, L.compact);
+			if (check_launch())
+			{
+				return -2;
+			}
+			ka.itemList = L.compact.defer_list;
+			ka.itemCount = L.compact.defer_count;
+		}
+		const int grid = std::min(nItemsX * L.flow_sets, std::max(L.wg_slots, 1));  // persistent workgroups
+		hipLaunchKernelGGL(edgeKern, dim3(grid), dim3(L.block), L.lds_bytes, s, ka);
+	}
+	else
+	{
+		using EdgeKern = decltype(&k_eval_edge_wg<true, true, 768>);
+		EdgeKern edgeKern = L.alias_lds ? (L.want_jac ? k_eval_edge_wg<true, true, 768> : k_eval_edge_wg<true, false, 768>)
+										: (L.want_jac ? k_eval_edge_wg<false, true, 768> : k_eval_edge_wg<false, false, 768>);
+		if (allow_big_lds(edgeKern, L.lds_bytes))
+		{
+			return -2;
+		}
+		hipLaunchKernelGGL(edgeKern, dim3(nItemsX, L.flow_sets), dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units, L.d_flows,
+						   L.want_jac, L.cap_px, L.fd_step, L.d_scratch, L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec,
+						   L.flow_sets == 1 ? L.d_modes : nullptr, live, EdgeCompact());
+	}
 	if (check_launch())
 	{
 		return -2;

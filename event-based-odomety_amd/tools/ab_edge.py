@@ -14,16 +14,21 @@ ev, offsets, gt = synth.make_stream(config, windows)
 ctx = ebo.Context(image_w=cfg["image"][0], image_h=cfg["image"][1], patch_w=cfg["patch"][0], patch_h=cfg["patch"][1],
                   loss=ebo.LOSS_EDGE, tv_weight=0.0, max_events=len(ev), max_windows=windows)
 stream = torch.cuda.current_stream(); ctx.set_stream(stream.cuda_stream); ctx.set_windows(ev, offsets)
-d_flows = torch.from_numpy(gt * 0.5).to("cuda")
+d_flows = torch.from_numpy(gt * float(os.environ.get("EBO_AB_FLOWSCALE", "0.5"))).to("cuda")
 d_out = torch.zeros((windows * ctx.P, 3), dtype=torch.float64, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+# a single setting is applied BEFORE the warm-up, so that every dispatch of the process runs under it (counter passes
+# average over all dispatches: tools/ab/edge_phase_mix.sh)
+if len(sys.argv) == 4:
+    for kv in filter(None, sys.argv[3].split(",")):
+        k, v = kv.split("="); os.environ[k] = v
 # clocks ramp up during the first few hundred milliseconds: without this the FIRST setting reads ~5 % slow
 for _ in range(200):
     ctx.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr())
 torch.cuda.synchronize()
 ref = None
 for st in sys.argv[3:] or [""]:
-    for k in ("EBO_EDGE_BLOCK", "EBO_EDGE_LDS_KB", "EBO_EDGE_ABLATE"):
+    for k in [k for k in os.environ if k.startswith("EBO_EDGE_")]:  # every switch of the setting before
         os.environ.pop(k, None)
     for kv in filter(None, st.split(",")):
         k, v = kv.split("="); os.environ[k] = v

@@ -261,3 +261,46 @@ def test_edge_direction_table_equals_rederived_tensor_sums(ebo, orc, synth, monk
         ok = ~np.isnan(Ja)
         scale = np.abs(Jb[ok]).max()
         assert np.abs(Ja[ok] - Jb[ok]).max() <= 1e-11 * scale
+
+
+@pytest.mark.parametrize("config,windows,kb", [(0, 6, "52"), (0, 6, "40"), (3, 2, "52")])
+def test_edge_compact_layout_and_deferred_units_keep_the_bits(ebo_ab, orc, synth, monkeypatch, config, windows, kb):
+    ebo = ebo_ab  # libebo_hip_ab.so: the build that reads the EBO_* switches (csrc/ab_env.h)
+    """Round 5: batches larger than the chip holds run two launches -- every unit on the compact LDS layout (16.5 B per
+    pixel: three workgroups per CU), units whose box does not fit deferred to a second launch on the 20 B layout.  Values
+    and Jacobians equal the single-launch path BIT FOR BIT at small, mid-solve and wild flows (all units compact / a mix /
+    mostly deferred, some of them on the global slice), value-only launches included, and the oracle to the usual bars."""
+    cfg = synth.CONFIGS[config]
+    ev, offsets, gt = synth.make_stream(config, windows)
+    rng = np.random.default_rng(5)
+    with ctx_for(ebo, synth, config, tv_weight=0.0, max_events=len(ev), max_windows=windows) as c:
+        c.set_windows(ev, offsets)
+        for scale in (0.0, 0.5, 1.0, 3.0):
+            flows = gt * scale + (0.0 if scale == 0.0 else 0.01 * rng.standard_normal(gt.shape))
+            monkeypatch.setenv("EBO_EDGE_COMPACT", "0")
+            r0, J0 = c.eval(flows)
+            v0, _ = c.eval(flows, want_jac=False)
+            monkeypatch.setenv("EBO_EDGE_COMPACT", "1")
+            monkeypatch.setenv("EBO_EDGE_COMPACT_KB", kb)
+            r1, J1 = c.eval(flows)
+            v1, _ = c.eval(flows, want_jac=False)
+            r2, J2 = c.eval(flows)  # and run to run
+            monkeypatch.delenv("EBO_EDGE_COMPACT_KB")
+            assert np.array_equal(r0, r1) and np.array_equal(J0, J1, equal_nan=True), scale
+            assert np.array_equal(v0, v1) and np.array_equal(r1, r2) and np.array_equal(J1, J2, equal_nan=True), scale
+            if scale in (0.5, 1.0):
+                ro, Jo, _, _ = orc.window_eval(ev[offsets[0]:offsets[1]], oparams(orc, c.params), flows[0])
+                check_rj(r1[0], J1[0], ro, Jo)
+
+
+def test_edge_large_batch_takes_the_compact_path_by_itself(ebo, orc, synth):
+    """The shipped library, no switch: 8 reference-default windows = 872 units > two workgroups per CU, so the evaluation
+    is the two-launch compact path; sampled windows against the oracle."""
+    ev, offsets, gt = synth.make_stream(0, 8)
+    with ctx_for(ebo, synth, 0, tv_weight=0.0, max_events=len(ev), max_windows=8) as c:
+        c.set_windows(ev, offsets)
+        flows = gt * 0.7
+        r, J = c.eval(flows)
+        for w in (0, 5):
+            ro, Jo, _, _ = orc.window_eval(ev[offsets[w]:offsets[w + 1]], oparams(orc, c.params), flows[w])
+            check_rj(r[w], J[w], ro, Jo)
