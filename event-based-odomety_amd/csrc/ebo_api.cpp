@@ -309,8 +309,13 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 		const bool eligible = L.alias_lds && L.block == 256 && !L.for_solve && L.flow_sets == 1 && !L.wide_kernel &&
 							  2 * L.lds_bytes <= 160 * 1024;
 		const size_t itemsNow = L.live.n > 0 ? static_cast<size_t>(L.live.n) * L.live.upw : items;  // a thinned-out lock-step round
-		const bool want = force ? std::atoi(force) != 0 : itemsNow > static_cast<size_t>(2) * c->n_cus;
-		if (eligible && want)
+		// (from eight units per CU up: measured on the reference-default lock-step call, the two launches of the compact
+		// path cost a 16-window solve +15 %, break even at 64 windows and save 9 % at 256 -- profiles/r05_edge_levers.txt)
+		const size_t atLeast = static_cast<size_t>(8) * c->n_cus;
+		const bool want = force ? std::atoi(force) != 0 : itemsNow > atLeast;
+		const bool wantFull = force ? std::atoi(force) != 0 : items > atLeast;  // ... some launch of this context
+		L.compact_table_px = 0;
+		if (eligible && wantFull)
 		{
 			const size_t budget = ab_size("EBO_EDGE_COMPACT_KB", 52) * 1024;
 			// red[128 doubles] | 80 ints | list (one int per 4 pixels + slack) | I, E (8 B each) | 4-bit counters
@@ -319,6 +324,10 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 			const size_t listCap = ((cap / 4 + 64) + 1) & ~static_cast<size_t>(1);
 			const size_t bytes = (168 + listCap / 2) * sizeof(double) + cap * 16 + cap / 2;
 			if (cap >= 1024 && bytes <= budget)
+			{
+				L.compact_table_px = static_cast<int>(cap);
+			}
+			if (cap >= 1024 && bytes <= budget && want)
 			{
 				if (c->edge_defer_cap < items + 1)
 				{
@@ -425,8 +434,10 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	L.ec.cs_stride = L.cap_px;
 	{
 		// (the compact launch keys its slots by unit, one workgroup each: the larger of the two launches' tables)
+		// (sized by the context's units, not by this launch's window list: the rounds of a lock-step solve must not
+		// flip between two sizes -- a reallocation synchronises the device)
 		const size_t need = std::max(static_cast<size_t>(L.wg_slots) * L.cap_px,
-									 L.compact.list_cap > 0 ? static_cast<size_t>(L.n_units) * L.compact_cap_px : 0) * 2 * sizeof(double);
+									 L.compact_table_px > 0 ? static_cast<size_t>(L.n_units) * L.compact_table_px : 0) * 2 * sizeof(double);
 		// The table is an optimisation nobody asked for by name, so it must not surprise: at most
 		// EBO_EDGE_CS_MB (default 4096) AND at most a quarter of the memory that is free right now
 		// (several contexts share a GPU: one per FeatureDetector / Optimizer / TrackedPatches of the

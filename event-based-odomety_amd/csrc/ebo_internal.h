@@ -214,6 +214,7 @@ struct EdgeLaunch
 	EdgeCompact compact;  // list_cap > 0: this launch uses the compact layout (edge_launch_setup)
 	size_t compact_lds_bytes = 0;
 	int compact_cap_px = 0;
+	int compact_table_px = 0;  // pixels per unit of the direction table whenever SOME launch of the context takes the compact layout
 	bool wide_kernel = false;  // A/B (EBO_EDGE_WIDE): the 168-VGPR instantiation whatever the workgroup size (three 256-lane workgroups per CU)
 	int wg_slots = 1;     // workgroups of a k_eval_edge launch (persistent: what the chip holds at once); k_solve_edge: one per unit
 	char* d_scratch;      // global fallback, [workgroup slot][stride]

@@ -294,13 +294,13 @@ def test_edge_compact_layout_and_deferred_units_keep_the_bits(ebo_ab, orc, synth
 
 
 def test_edge_large_batch_takes_the_compact_path_by_itself(ebo, orc, synth):
-    """The shipped library, no switch: 8 reference-default windows = 872 units > two workgroups per CU, so the evaluation
+    """The shipped library, no switch: 24 reference-default windows = 2616 units > eight per CU, so the evaluation
     is the two-launch compact path; sampled windows against the oracle."""
-    ev, offsets, gt = synth.make_stream(0, 8)
-    with ctx_for(ebo, synth, 0, tv_weight=0.0, max_events=len(ev), max_windows=8) as c:
+    ev, offsets, gt = synth.make_stream(0, 24)
+    with ctx_for(ebo, synth, 0, tv_weight=0.0, max_events=len(ev), max_windows=24) as c:
         c.set_windows(ev, offsets)
         flows = gt * 0.7
         r, J = c.eval(flows)
-        for w in (0, 5):
+        for w in (0, 17):
             ro, Jo, _, _ = orc.window_eval(ev[offsets[w]:offsets[w + 1]], oparams(orc, c.params), flows[w])
             check_rj(r[w], J[w], ro, Jo)
