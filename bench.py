@@ -90,9 +90,33 @@ def cpu_baseline(synth, cfg_idx, seconds_budget):
     sec, n = orc.window_eval_timed(ev, prm, flows, True, reps)
     base = {
         "value": n / sec / 1e6, "unit": "Mevents/s", "cores": 1, "kind": "port",
+        "flags": "-O2 -ffp-contract=off (oracle/liboracle.so, the tests' checker)",
         "sample": "%d value+Jacobian evaluations of 1 window of %s (%d event-evaluations, %.1f s) "
                   "by oracle/liboracle.so, single thread like the reference" % (reps, cfg["name"], n, sec),
     }
+    # The same sample on the reference's own optimisation flags (CMakeLists.txt:43,57-60: -O3 -DNDEBUG -march=native),
+    # built HERE, on the machine that runs it, into a scratch directory; -ffp-contract=off kept (oracle/Makefile).
+    try:
+        import ctypes as C
+        import subprocess
+        import tempfile
+        scratch = tempfile.mkdtemp(prefix="ebo_oracle_")
+        so = os.path.join(scratch, "liboracle_ref_flags.so")
+        subprocess.check_call(["make", "-s", "-B", "-C", orc.ORACLE_DIR, "liboracle_ref_flags.so", "OUT_REF=" + so],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        fast = C.CDLL(so)
+        evc = np.ascontiguousarray(ev, dtype=orc.EVENT_DTYPE)
+        fl = np.ascontiguousarray(flows, dtype=np.float64)
+        s2, c2 = C.c_double(), C.c_uint64()
+        for r in (1, reps):
+            rc = fast.orc_window_eval_timed(evc.ctypes.data_as(C.c_void_p), C.c_size_t(len(evc)), C.byref(prm),
+                                            fl.ctypes.data_as(C.POINTER(C.c_double)), 1, int(r), C.byref(s2), C.byref(c2))
+            assert rc == 0
+        base["value_ref_flags"] = c2.value / s2.value / 1e6
+        base["flags_ref"] = "-O3 -DNDEBUG -march=native -ffp-contract=off (the reference's CMakeLists.txt:43,57-60), built on this host"
+    except Exception as exc:  # a reported extra: the -O2 figure above stands
+        base["value_ref_flags"] = None
+        base["flags_ref"] = "not built: %r" % (exc,)
     legs = {}
     # (ii) a full per-patch solve of one window (the reference-default configuration: 15 k events,
     # 108 patches of 20x20, the solve the `c4` workload runs per shard), event-evaluations/s
@@ -936,6 +960,39 @@ def main():
             "compact8_upload_pinned_plus_device_bucketing": n_events / t_c8 / 1e6,
             "device_bucketing_resident_events": n_events / t_res / 1e6}
         del d_raw, pin8, pin24
+
+        # text ingest: a DAVIS events.txt of the window's events, parsed by the library on the host's
+        # threads (csrc/txt_events.h; the reference reads with hardware_concurrency() threads as well) -- lines per
+        # second with one thread and with the default thread count, and the thread count that parsed
+        try:
+            import tempfile
+            n_lines = 2_000_000
+            rng_t = np.random.default_rng(11)
+            tcol = 1468941032.0 + np.cumsum(rng_t.integers(0, 50, n_lines)) * 1e-6
+            xs, ys, ss = rng_t.integers(0, 346, n_lines), rng_t.integers(0, 260, n_lines), rng_t.integers(0, 2, n_lines)
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "events.txt")
+                with open(path, "w") as fh:
+                    for lo in range(0, n_lines, 200_000):
+                        hi = lo + 200_000
+                        fh.write("".join("%.6f %d %d %d\n" % q for q in zip(tcol[lo:hi], xs[lo:hi], ys[lo:hi], ss[lo:hi])))
+                buf = np.zeros(n_lines, dtype=ebo.EVENT_DTYPE)
+                res = {}
+                for label_t, thr in (("one_thread", 1), ("default_threads", 0)):
+                    best, used = None, 1
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        got, _, used = ebo.read_events_txt_threads(path, n_lines, thr, out=buf)
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None else min(best, dt)
+                    assert len(got) == n_lines
+                    res[label_t] = {"mlines_per_s": n_lines / best / 1e6, "threads": used}
+                res["file_mb"] = os.path.getsize(path) / 1e6
+                res["lines"] = n_lines
+                res["host_cpus"] = len(os.sched_getaffinity(0))
+            extras["text_ingest_mlines_per_s"] = res
+        except Exception as exc:  # a reported extra
+            extras["text_ingest_mlines_per_s"] = {"error": repr(exc)}
 
         def eval_extra(ci, wn, loss, label, reps=10, cfgd=None):
             """value+Jacobian evaluation of `wn` windows of config ci with `loss`"""

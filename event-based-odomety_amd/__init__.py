@@ -309,6 +309,21 @@ def read_events_txt(path, cap=1 << 22):
     return out[: n.value].copy()
 
 
+def read_events_txt_threads(path, cap, threads=0, offset=None, out=None):
+    """ebo_read_events_txt_threads: at most cap events with `threads` host threads (0: EBO_HOST_THREADS or the
+    machine's) -> (events, next offset or None, threads that parsed).  `out`: a caller-owned array to fill (timing)."""
+    out = np.zeros(cap, dtype=EVENT_DTYPE) if out is None else out
+    n, used = C.c_size_t(), C.c_int()
+    off = C.c_uint64(int(offset)) if offset is not None else None
+    f = lib().ebo_read_events_txt_threads
+    f.restype = C.c_int
+    rc = f(str(path).encode(), C.byref(off) if off is not None else None, _vp(out), C.c_size_t(cap), C.byref(n),
+           C.c_int(int(threads)), C.byref(used))
+    if rc:
+        raise EboError(rc, "cannot parse %s (parsed %d events before the error)" % (path, n.value))
+    return out[: n.value], (int(off.value) if off is not None else None), int(used.value)
+
+
 def read_events_txt_at(path, offset, cap=1_000_000):
     """At most cap events of an events.txt from byte `offset` on -> (events, next offset): the pieces
     Davis240cReader::getEvents reads a recording in (EVENT_LENGTH lines per call)."""

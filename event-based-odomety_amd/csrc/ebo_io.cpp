@@ -1,13 +1,14 @@
 // ebo_io.cpp — DAVIS events.txt reader and the packed binary sidecar (include/ebo.h).
 #include "ebo_ctx.h"
+#include "txt_events.h"
 
 using namespace ebo;
 
 extern "C" {
 
 // ---- packed binary sidecar of an events.txt -------------------------------
-// Parsing the text format costs ~100 ns per event (strtod): at device rates the recording, not
-// the GPU, is the bottleneck.  The sidecar stores what Davis240cReader::getEventSample produces
+// Parsing the text format costs tens of nanoseconds per event and host thread (csrc/txt_events.h): at device rates
+// the recording, not the GPU, is the bottleneck.  The sidecar stores what Davis240cReader::getEventSample produces
 // from each line -- the microsecond timestamp AFTER the double -> int64 truncation, x, y, sign --
 // so reading it back gives bit-identical events with no parsing.
 //   header (32 B): magic "EBOEVT1\0", uint64 n_events, uint32 record_bytes (= 16), uint32 flags (0),
@@ -134,121 +135,12 @@ int ebo_read_events_bin(const char* path, ebo_event* out, size_t cap, size_t* n)
 	return rc;
 }
 
-// DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one
-// event per line "<seconds> <x> <y> <0|1>".  Seconds go through a double and are
-// truncated to microseconds, exactly as std::stod + duration_cast do there.
-namespace
-{
-// at most cap events from byte *offset on (null: from the start); *offset moves behind the last line taken
-int read_events_txt(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n)
-{
-	if (!path || !n || (cap && !out))
-	{
-		return EBO_ERR_ARG;
-	}
-	*n = 0;
-	FILE* fp = std::fopen(path, "rb");
-	if (!fp)
-	{
-		return EBO_ERR_ARG;
-	}
-	uint64_t pos = offset ? *offset : 0;  // first byte not yet consumed
-	if (pos && fseeko(fp, static_cast<off_t>(pos), SEEK_SET) != 0)
-	{
-		std::fclose(fp);
-		return EBO_ERR_ARG;
-	}
-	std::vector<char> buf(1 << 20);
-	std::string line;
-	size_t count = 0;
-	int rc = EBO_OK;
-	// true: the line is consumed (an event, or blank); false: stop in front of it
-	auto take = [&](const std::string& ln) -> bool {
-		const char* s = ln.c_str();
-		char* end = nullptr;
-		const double sec = std::strtod(s, &end);
-		if (end == s)
-		{
-			return true;  // blank line
-		}
-		const char* p = end;
-		const long x = std::strtol(p, &end, 10);
-		if (end == p)
-		{
-			rc = EBO_ERR_RANGE;
-			return false;
-		}
-		p = end;
-		const long y = std::strtol(p, &end, 10);
-		if (end == p)
-		{
-			rc = EBO_ERR_RANGE;
-			return false;
-		}
-		p = end;
-		const long sign = std::strtol(p, &end, 10);
-		if (end == p || (sign != 0 && sign != 1))
-		{
-			rc = EBO_ERR_RANGE;  // "Sign is not equal to 0/1" (:85-88)
-			return false;
-		}
-		if (count >= cap)
-		{
-			return false;
-		}
-		ebo_event& e = out[count++];
-		e.x = static_cast<int32_t>(x);
-		e.y = static_cast<int32_t>(y);
-		e.sign = sign == 0 ? -1 : 1;
-		e.reserved = 0;
-		e.t_us = static_cast<int64_t>(sec * 1000000.0);
-		return true;
-	};
-	bool go = true;
-	while (go)
-	{
-		const size_t got = std::fread(buf.data(), 1, buf.size(), fp);
-		if (got == 0)
-		{
-			break;
-		}
-		size_t start = 0;
-		for (size_t i = 0; i < got && go; ++i)
-		{
-			if (buf[i] == '\n')
-			{
-				line.append(buf.data() + start, i - start);
-				go = take(line);
-				if (go)
-				{
-					pos += line.size() + 1;
-				}
-				line.clear();
-				start = i + 1;
-			}
-		}
-		if (go)
-		{
-			line.append(buf.data() + start, got - start);
-		}
-	}
-	if (go && !line.empty() && take(line))
-	{
-		pos += line.size();  // a last line without a newline
-	}
-	std::fclose(fp);
-	*n = count;
-	if (offset)
-	{
-		*offset = pos;
-	}
-	return rc;
-}
-}  // namespace
-
+// DAVIS240C events.txt (tools/dataset_reader/src/davis240c_reader.cpp:60-92): one event per line
+// "<seconds> <x> <y> <0|1>".  The reader itself -- mapped file, one chunk per host thread, the fast and the strtod path
+// of a line -- is csrc/txt_events.h (HIP-free, tested on the CPU under ThreadSanitizer).
 int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
 {
-	return read_events_txt(path, nullptr, out, cap, n);
+	return ebo::txt::read_events_file(path, nullptr, out, cap, n, 0);
 }
 
 int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n)
@@ -257,7 +149,23 @@ int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, s
 	{
 		return EBO_ERR_ARG;
 	}
-	return read_events_txt(path, offset, out, cap, n);
+	return ebo::txt::read_events_file(path, offset, out, cap, n, 0);
+}
+
+int ebo_read_events_txt_threads(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n, int threads,
+								int* threads_used)
+{
+	if (threads < 0)
+	{
+		return EBO_ERR_ARG;
+	}
+	unsigned used = 1;
+	const int rc = ebo::txt::read_events_file(path, offset, out, cap, n, static_cast<unsigned>(threads), &used);
+	if (threads_used)
+	{
+		*threads_used = static_cast<int>(used);
+	}
+	return rc;
 }
 
 // trajectory.txt of tools::Evaluator::saveFeaturesTrajectory (tools/evaluator/src/evaluator.cpp:125-150):

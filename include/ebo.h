@@ -495,6 +495,14 @@ int ebo_read_events_txt(const char* path, ebo_event* out, size_t cap, size_t* n)
  * 1 000 000 lines per call, the next call continues behind them): at most cap events from byte *offset of the file on;
  * *offset moves behind the last line taken (start with 0; *n == 0 with EBO_OK = the end of the file). */
 int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n);
+/* Both of them parse on the host's threads since round 5, as the reference's reader does (DatasetReader::readFile,
+ * tools/dataset_reader/include/dataset_reader/dataset_reader.h:33-97: hardware_concurrency() threads over the mapped
+ * file): the mapped byte range is cut at line breaks into one chunk per thread (EBO_HOST_THREADS, default: the
+ * machine's hardware threads).  Events, *n, *offset and the error are those of a single-thread walk whatever the
+ * thread count.  This form takes the thread count from the caller (0: the default; offset may be NULL) and reports
+ * how many threads parsed (threads_used, may be NULL). */
+int ebo_read_events_txt_threads(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n, int threads,
+								int* threads_used);
 
 /* Contiguous shard [begin,end) of n_units for rank of world (multi-GPU, §8e). */
 int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end);

@@ -164,3 +164,30 @@ def test_config1_through_the_hip_path(ebo, orc, stream_file, loss):
         assert np.array_equal(img, orc.final_count_image(ev[a:b], prm, flows))
         integ = c.count_image(ebo.COUNT_INTEGRATED)[0]
         assert np.array_equal(integ, orc.integrate_events(ev[a:b], 240, 180))
+
+
+def test_threaded_reader_entry_point_on_the_reference_fixture(ebo, tmp_path):
+    """ebo_read_events_txt_threads on the reference's own fixture (davis240c_reader_test.cpp:19-48's five events) with 1
+    and 8 threads asked (a five-line file is parsed by one), and on a file large enough for several threads against
+    the default entry point."""
+    fx = os.path.join(HERE, "golden", "davis_events_fixture.txt")
+    want = ebo.read_events_txt(fx)
+    assert len(want) == 5
+    for threads in (1, 8):
+        got, _, used = ebo.read_events_txt_threads(fx, 16, threads)
+        assert used == 1 and np.array_equal(got, want)
+    rng = np.random.default_rng(3)
+    n = 120_000
+    t = 5.0 + np.cumsum(rng.integers(0, 40, n)) * 1e-6
+    p = tmp_path / "events.txt"
+    with open(p, "w") as f:
+        f.write("".join("%.6f %d %d %d\n" % (a, b, c, d) for a, b, c, d in
+                        zip(t, rng.integers(0, 240, n), rng.integers(0, 180, n), rng.integers(0, 2, n))))
+    whole = ebo.read_events_txt(str(p))
+    assert len(whole) == n
+    got, off, used = ebo.read_events_txt_threads(str(p), n, 4, offset=0)
+    assert used >= 2 and off == os.path.getsize(p) and np.array_equal(got, whole)
+    one, _, used1 = ebo.read_events_txt_threads(str(p), n, 1)
+    assert used1 == 1 and np.array_equal(one, whole)
+    # microseconds: the seconds column through a double, truncated (duration_cast) -- an independent restatement
+    assert np.array_equal(whole["t_us"], (np.array([float("%.6f" % a) for a in t]) * 1e6).astype(np.int64))

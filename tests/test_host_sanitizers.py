@@ -59,3 +59,33 @@ def test_host_lm_trajectories_keep_their_bits(no_avx2):
     out = subprocess.run([os.path.join(CPP, "hostlm_golden")], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "as pinned" in out.stdout
+
+
+def _run_txt(binary, lines):
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ)
+        env.setdefault("TSAN_OPTIONS", "halt_on_error=1")
+        out = subprocess.run([os.path.join(CPP, binary), d, str(lines)], env=env, capture_output=True, text=True, timeout=900)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "txt_events_stress: OK" in out.stdout, text[-3000:]
+    for bad in ("ThreadSanitizer", "AddressSanitizer", "runtime error"):
+        assert bad not in text, text[-3000:]
+    return out.stdout
+
+
+def test_parallel_events_txt_reader_equals_the_single_thread_reader():
+    """Round 5: csrc/txt_events.h parses an events.txt on the host's threads, as the reference's
+    reader does (dataset_reader.h:33-97).  Against the single-thread reader of rounds 1-4 (kept in the test): the same
+    events, count, byte offset and status for 24 mixed files (blank lines, comments, CRLF, exponents, signs, tabs,
+    mantissas above 2^53, a malformed line, no trailing newline) x 1..16 threads x caps around the merge's edge cases
+    and chains of offsets, and a 10 M-line canonical file bit for bit -- also read in the reference's pieces of
+    1 000 000 lines; the rates are printed."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "txt_events_stress"])
+    text = _run_txt("txt_events_stress", 10_000_000)
+    print(text[-900:])
+
+
+def test_parallel_events_txt_reader_under_thread_sanitizer():
+    subprocess.check_call(["make", "-s", "-C", CPP, "txt_events_stress_tsan"])
+    _run_txt("txt_events_stress_tsan", 200_000)
