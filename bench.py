@@ -53,6 +53,9 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 T_START = time.time() - 2.0  # files of the id hand-over older than this run are somebody else's
+# how long a rank waits for another rank's file of the id hand-over / the vote (rank 0 comes from its CPU baseline,
+# 10-40 s later than the others): beyond it the library's communicator counts as failed on that rank
+COMM_TIMEOUT_S = float(os.environ.get("EBO_BENCH_COMM_TIMEOUT_S", "120"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X spec: f64 vector FMA, 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
 # Useful f64 operations of one edge-loss evaluation per item of work (DESIGN.md 4.5 derives them from
@@ -228,16 +231,44 @@ def _free_port():
     return port
 
 
+def run_children(cmd, env, deadline_s):
+    """Run `cmd` as a child in its OWN session and wait at most deadline_s for it: beyond that its process group --
+    exactly the processes this call started -- is ended (SIGTERM, then SIGKILL) and the call returns 124 after a
+    one-line diagnosis on stderr.  A multi-rank run that hangs on first contact (a communicator that never comes up,
+    a rank that never reaches a collective) must end as a failed run with a reason, below the time the driver gives a
+    bench, not as a silent time-limit kill."""
+    import signal
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=deadline_s)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the ranks did not finish within %.0f s (EBO_BENCH_DEADLINE_S) -- ending them; "
+                         "no result line\n" % deadline_s)
+        sys.stderr.flush()
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(proc.pid, sig)  # the session this call created: pgid == the child's pid
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD
     processes (torch.distributed.run) before this process has touched the GPU, relay their output,
-    exit with their code.  Nothing is exec'ed and this process never initialises HIP."""
+    exit with their code.  Nothing is exec'ed and this process never initialises HIP.  The children get
+    EBO_BENCH_DEADLINE_S seconds (default 540: below the driver's 600) before they are ended with a diagnosis."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "4")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return run_children(cmd, env, float(os.environ.get("EBO_BENCH_DEADLINE_S", "540")))
 
 
 class TorchComm:
@@ -354,8 +385,16 @@ class EboComm:
         self.prefix = os.path.join("/tmp", "ebo_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
 
     def attach(self, ctx):
-        cid = self.ebo.comm_unique_id() if self.rank == 0 else None
-        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid, timeout=900.0, not_before=T_START)  # rank 0 arrives after its CPU baseline
+        cid, why = None, None
+        if self.rank == 0:
+            try:
+                cid = self.ebo.comm_unique_id()
+            except Exception as exc:  # librccl not loadable, ncclGetUniqueId failed: the other ranks must learn it NOW
+                why = exc
+        # (rank 0 arrives after its CPU baseline, seconds later than the others; a failed id is handed over as such)
+        cid = self.exchange.handover_bytes(self.prefix, self.rank, self.world, cid, timeout=COMM_TIMEOUT_S, not_before=T_START)
+        if why is not None:
+            raise why
         ctx.comm_init(cid, self.rank, self.world)
         self.ctx = ctx
         self.d_one = self.torch.zeros(1, dtype=self.torch.float64, device="cuda")
@@ -443,10 +482,13 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="same as --workload replicas (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--comm", choices=("auto", "ebo", "torch"), default="auto",
-                    help="N > 1 transport: ebo = the library's own RCCL communicator (ebo_comm_init: ebo_allgather_device, "
-                         "ebo_band_exchange_device, ebo_allgather_tracks), torch = torch.distributed; auto = ebo, and torch when "
-                         "the library's communicator cannot be set up on every rank (a rehearsal over gloo is always torch)")
+    ap.add_argument("--comm", choices=("auto", "ebo", "torch"), default="torch",
+                    help="N > 1 transport: torch = torch.distributed (backend nccl = RCCL; the default since round 5: the "
+                         "library's grouped ncclSend / ncclRecv have never run between two ranks -- no box with two GPUs was "
+                         "available -- and a deadlock inside the probe step is the one failure no fallback can rescue); "
+                         "ebo = the library's own RCCL communicator (ebo_comm_init: ebo_allgather_device, "
+                         "ebo_band_exchange_device, ebo_allgather_tracks); auto = ebo after one probed step and a vote, torch "
+                         "when any rank says no (a rehearsal over gloo is always torch)")
     ap.add_argument("--c4-image", choices=("band", "dense"), default="band",
                     help="c4 final image: band = every rank keeps its own rows, only halo rows travel to the two neighbours "
                          "(SURVEY 8(e)); dense = a full image per window from every rank reduced onto rank 0 (round 3)")
@@ -534,7 +576,11 @@ def main():
                 if not ok:
                     raise SystemExit("--comm ebo: the library's communicator failed on rank %d: %s" % (rank, why))
                 return cand
-            if exchange.agree(cand.prefix, rank, world, ok, timeout=900.0, not_before=T_START):
+            try:
+                agreed = exchange.agree(cand.prefix, rank, world, ok, timeout=COMM_TIMEOUT_S, not_before=T_START)
+            except TimeoutError as exc:  # a rank that never voted is a `no` -- and every rank sees it as one
+                agreed, why = False, "%s; %r" % (why, exc)
+            if agreed:
                 return cand
             comm_notes["fallback"] = "the library's communicator could not be set up and run one step on every rank (%s): torch.distributed" % (why,)
             try:

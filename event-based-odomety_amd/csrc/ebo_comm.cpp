@@ -472,10 +472,12 @@ int ebo_band_exchange_device(ebo_ctx* c, int n_windows, const ebo_band* band, co
 	{
 		return c->fail(EBO_ERR_ARG, "bad argument to ebo_band_exchange_device");
 	}
-	if (!c->comm || c->comm_size == 1)
+	if (!c->comm)
 	{
-		return EBO_OK;  // one rank: nothing travels, its own flag is the verdict
+		return EBO_OK;  // no communicator: nothing travels, the rank's own flag is the verdict
 	}
+	// (a communicator of ONE rank takes the same calls -- an empty group and the reduction of the flag -- so that the one
+	// rank a single-GPU box allows runs the code N ranks run, tests/test_gpu_comm.py)
 	const size_t W = static_cast<size_t>(c->prm.image_w), nw = static_cast<size_t>(n_windows);
 	const size_t up = static_cast<size_t>(band->own_row0 - band->band_row0) * W * nw;
 	const size_t down = static_cast<size_t>(band->band_row1 - band->own_row1) * W * nw;
@@ -534,12 +536,13 @@ int ebo_band_gather_device(ebo_ctx* c, int n_windows, const int* row_bounds, con
 	{
 		return c->fail(EBO_ERR_ARG, "null own image");
 	}
-	if (nr == 1)
+	if (!c->comm)
 	{
 		return c->hip(hipMemcpyAsync(d_full, d_image_own, static_cast<size_t>(n_windows) * H * W * sizeof(double), hipMemcpyDeviceToDevice,
 									 c->stream),
 					  "own image -> full image");
 	}
+	// (a communicator of one rank sends to and receives from itself inside the group: the code path of N ranks)
 	std::string err;
 	RcclApi* api = rccl_api(err);
 	int nrc = api->GroupStart();
@@ -589,6 +592,25 @@ int ebo_comm_destroy(ebo_ctx* c)
 		}
 		c->comm = nullptr;
 	}
+	// what ebo_comm_init and the exchanges allocated goes with the communicator (it used to wait for the next
+	// ebo_comm_init: a destroyed context leaked device and pinned memory)
+	if (c->d_comm_cnt || c->d_comm_buf || c->pin_comm)
+	{
+		(void)hipSetDevice(c->prm.device);
+		(void)hipStreamSynchronize(c->stream);
+		hipFree(c->d_comm_cnt);
+		c->d_comm_cnt = nullptr;
+		hipFree(c->d_comm_buf);
+		c->d_comm_buf = nullptr;
+		c->comm_buf_cap = 0;
+		if (c->pin_comm)
+		{
+			hipHostFree(c->pin_comm);
+			c->pin_comm = nullptr;
+		}
+	}
+	c->comm_rank = 0;
+	c->comm_size = 1;
 	return EBO_OK;
 }
 

@@ -101,53 +101,77 @@ def halo_exchange(top, bottom, from_above, from_below, flag, group=None):
     return flag
 
 
+FAILED_ID = b"EBO-NO-ID"  # what rank 0 hands over when it could not make an id: the others fail at once instead of waiting
+
+
 def handover_bytes(prefix, rank, world, payload=None, timeout=120.0, not_before=None):
     """Rank 0's `payload` (bytes: the 128-byte id of ebo_comm_unique_id) on every rank of one node, through the
     file `prefix`.id written atomically by rank 0 -- no framework, no sockets.  Then every rank leaves a mark
     (`prefix`.got.<rank>); rank 0 removes the files once all marks are there.  not_before (seconds since the epoch,
-    e.g. the time this process started): a file older than that is what a crashed earlier run left behind under the
-    same name and is ignored (rank 0 replaces it)."""
+    e.g. the time this process started): a file older than that -- the id OR a mark -- is what a crashed earlier run
+    left behind under the same name and is ignored (rank 0 replaces the id and removes stale marks before it writes).
+    Rank 0 ALWAYS publishes something: payload None / FAILED_ID says "no id" and every rank raises RuntimeError at
+    once (the caller votes `no`), instead of the other ranks waiting out their timeout."""
     import os
     import time
     path = prefix + ".id"
 
-    def fresh():
+    def fresh(p):
         try:
-            return os.path.exists(path) and (not_before is None or os.path.getmtime(path) >= not_before)
+            return os.path.exists(p) and (not_before is None or os.path.getmtime(p) >= not_before)
         except OSError:
             return False
     if rank == 0:
-        if payload is None:
-            raise ValueError("rank 0 hands the payload over")
+        for q in range(world):  # marks of a crashed run must not let this run delete the id before a slow rank read it
+            try:
+                os.remove("%s.got.%d" % (prefix, q))
+            except OSError:
+                pass
         tmp = path + ".tmp.%d" % os.getpid()
         with open(tmp, "wb") as fp:
-            fp.write(payload)
+            fp.write(payload if payload is not None else FAILED_ID)
         os.replace(tmp, path)
     t0 = time.time()
-    while not fresh():
+    while not fresh(path):
         if time.time() - t0 > timeout:
-            raise TimeoutError("no %s after %.0f s" % (path, timeout))
+            raise TimeoutError("no %s after %.0f s (rank 0 never handed its id over)" % (path, timeout))
         time.sleep(0.01)
     with open(path, "rb") as fp:
         got = fp.read()
     open("%s.got.%d" % (prefix, rank), "wb").close()
     if rank == 0:
-        while not all(os.path.exists("%s.got.%d" % (prefix, q)) for q in range(world)):
+        while not all(fresh("%s.got.%d" % (prefix, q)) for q in range(world)):
             if time.time() - t0 > timeout:
-                raise TimeoutError("a rank never read %s" % path)
+                missing = [q for q in range(world) if not fresh("%s.got.%d" % (prefix, q))]
+                raise TimeoutError("rank(s) %s never read %s within %.0f s" % (missing, path, timeout))
             time.sleep(0.01)
         for q in range(world):
             os.remove("%s.got.%d" % (prefix, q))
         os.remove(path)
+    if got == FAILED_ID:
+        raise RuntimeError("rank 0 could not make a communicator id")
     return got
 
 
+_AGREE_ROUND = {}
+
+
 def agree(prefix, rank, world, ok, timeout=120.0, not_before=None):
-    """Every rank's yes / no on every rank (files `prefix`.ok.<rank>): True when all said yes.  For decisions every
-    rank must take the same way BEFORE any collective exists (does the library's communicator work here?)."""
+    """Every rank's yes / no on every rank (files `prefix`.ok.<round>.<rank>): True when all said yes.  For decisions
+    every rank must take the same way BEFORE any collective exists (does the library's communicator work here?).
+    The round number (how often this process has voted under this prefix: the same on every rank) keeps a second
+    vote from reading the first one's files; a rank removes its own file of the round before.  TimeoutError names
+    the rank that never voted."""
     import os
     import time
-    mine = "%s.ok.%d" % (prefix, rank)
+    rnd = _AGREE_ROUND.get(prefix, 0)
+    _AGREE_ROUND[prefix] = rnd + 1
+    mine = "%s.ok.%d.%d" % (prefix, rnd, rank)
+    if rnd > 0:
+        try:
+            os.remove("%s.ok.%d.%d" % (prefix, rnd - 1, rank))
+        except OSError:
+            pass
     tmp = mine + ".tmp"
     with open(tmp, "w") as fp:
         fp.write("1" if ok else "0")
@@ -155,10 +179,10 @@ def agree(prefix, rank, world, ok, timeout=120.0, not_before=None):
     t0 = time.time()
     votes = []
     for q in range(world):
-        p = "%s.ok.%d" % (prefix, q)
+        p = "%s.ok.%d.%d" % (prefix, rnd, q)
         while not (os.path.exists(p) and (not_before is None or os.path.getmtime(p) >= not_before)):
             if time.time() - t0 > timeout:
-                raise TimeoutError("rank %d never voted" % q)
+                raise TimeoutError("rank %d never voted within %.0f s (%s)" % (q, timeout, p))
             time.sleep(0.01)
         with open(p) as fp:
             votes.append(fp.read().strip() == "1")

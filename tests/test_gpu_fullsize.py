@@ -14,6 +14,8 @@ sampled oracle checks.
 import numpy as np
 import pytest
 
+from jac_check import assert_jac_close
+
 pytestmark = pytest.mark.gpu
 
 FULL = [(2, 50_000), (3, 200_000), (4, 1_000_000)]
@@ -79,11 +81,17 @@ def test_count_images_full_size(ebo, orc, synth, config, n_events):
         assert np.array_equal(parts[0] + parts[1], ref)
 
 
+@pytest.mark.parametrize("loss_name", ["variance", "edge"])
 @pytest.mark.parametrize("config,n_events", FULL)
-def test_objective_full_size_properties(ebo, orc, synth, config, n_events):
+def test_objective_full_size_properties(ebo, orc, synth, config, n_events, loss_name):
+    """Both losses (round 5: the edge loss -- the reference's active one -- as well, incl. C3's 21x16 grid with its
+    31-wide last column and C4's 40x22 patches on the 20 B layout): determinism, permutation invariance, batch = alone,
+    and sampled patches -- always including the remainder column / row / corner patches -- against the oracle."""
     ev, gt = synth.make_window(config)
     flows = gt * 0.5
-    with ctx_for(ebo, synth, config, max_events=2 * n_events, max_windows=2) as c:
+    edge = loss_name == "edge"
+    with ctx_for(ebo, synth, config, max_events=2 * n_events, max_windows=2,
+                 loss=ebo.LOSS_EDGE if edge else ebo.LOSS_VARIANCE) as c:
         c.set_window(ev)
         r, J = c.eval(flows)
         r2, J2 = c.eval(flows)
@@ -103,8 +111,9 @@ def test_objective_full_size_properties(ebo, orc, synth, config, n_events):
         assert np.array_equal(rb[1], r[0]) and np.array_equal(Jb[1], J[0])
         # a sample of patches against the oracle on exactly their events
         c.set_window(ev)
-        sample = rng.choice(c.P, size=min(12, c.P), replace=False)
-        for p in sample:
+        sample = set(int(q) for q in rng.choice(c.P, size=min(12, c.P), replace=False))
+        sample |= {c.npx - 1, (c.npy - 1) * c.npx, c.P - 1}  # last column, last row, corner: the grid's remainder patches
+        for p in sorted(sample):
             x0, y0, pw, ph = c.patch_rect(p % c.npx, p // c.npx)
             sel = (ev["x"] >= x0) & (ev["x"] < x0 + pw) & (ev["y"] >= y0) & (ev["y"] < y0 + ph)
             n, active, _ = c.patch_info(p)
@@ -112,9 +121,12 @@ def test_objective_full_size_properties(ebo, orc, synth, config, n_events):
             if not active:
                 assert r[0][p] == 0.0
                 continue
-            ro, Jo = orc.contrast_eval(ev[sel], (x0, y0, pw, ph), flows[p], 1)
+            ro, Jo = orc.contrast_eval(ev[sel], (x0, y0, pw, ph), flows[p], 0 if edge else 1)
             np.testing.assert_allclose(r[0][p], ro, rtol=1e-9)
-            np.testing.assert_allclose(J[0][p], Jo, rtol=1e-9, atol=1e-10)
+            if edge:
+                assert_jac_close(J[0][p], Jo, rtol=1e-8)
+            else:
+                np.testing.assert_allclose(J[0][p], Jo, rtol=1e-9, atol=1e-10)
 
 
 def test_device_solve_full_size_is_deterministic_and_lowers_the_cost(ebo, synth):

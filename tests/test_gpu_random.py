@@ -6,6 +6,8 @@ events leave the 3x canvas, the 32-bit counter path)."""
 import numpy as np
 import pytest
 
+from jac_check import assert_jac_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -83,14 +85,17 @@ def test_random_windows_match_the_oracle(ebo, ebo_ab, monkeypatch, orc, seed):
                     # diagnostic: per-pixel sums in list order, one rounding per event); every other patch must
                     # agree to the tolerance of every other flow.
                     act = active.astype(bool)
-                    tie = (np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-7).any(axis=1) & act
-                    np.testing.assert_allclose(J[0][~tie], Jo[~tie], rtol=tol, atol=1e-7)
+                    tie = (np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-8 * np.abs(Jo).max(axis=1, keepdims=True) + 1e-13).any(axis=1) & act
+                    assert_jac_close(J[0][~tie], Jo[~tie], rtol=tol) if loss == ebo.LOSS_EDGE else np.testing.assert_allclose(J[0][~tie], Jo[~tie], rtol=tol, atol=1e-7)
                     for q in np.flatnonzero(tie):
                         rq, Jq = reference_order_eval(ebo_ab, monkeypatch, cs, ev, c.patch_rect(q % c.npx, q // c.npx), p.min_events)
                         np.testing.assert_allclose(rq, ro[q], rtol=1e-12, atol=1e-9)
-                        np.testing.assert_allclose(Jq, Jo[q], rtol=1e-8, atol=1e-7)
+                        assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
                     continue
-                np.testing.assert_allclose(J[0], Jo, rtol=tol, atol=1e-7)
+                if loss == ebo.LOSS_EDGE:
+                    assert_jac_close(J[0], Jo, rtol=tol)
+                else:
+                    np.testing.assert_allclose(J[0], Jo, rtol=tol, atol=1e-7)
             if loss == ebo.LOSS_VARIANCE:
                 flows = rng.uniform(-3, 3, (P, 2))
                 field = rng.uniform(-3, 3, (cs["h"], cs["w"], 2)).astype(np.float32)
@@ -121,11 +126,11 @@ def test_edge_jacobian_at_exact_ties(ebo, ebo_ab, monkeypatch, orc):
             r, J = c.eval(flows)
             ro, Jo, active, _ = orc.window_eval(ev, prm, flows)
             np.testing.assert_allclose(r[0], ro, rtol=1e-9, atol=1e-9)
-            d = (np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-7).any(axis=1) & active.astype(bool)
+            d = (np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-8 * np.abs(Jo).max(axis=1, keepdims=True) + 1e-13).any(axis=1) & active.astype(bool)
             # every patch that differs is a tie of the image sums' last bits: built the reference's way, it agrees
             for q in np.flatnonzero(d):
                 rq, Jq = reference_order_eval(ebo_ab, monkeypatch, cs, ev, c.patch_rect(q % c.npx, q // c.npx), 3)
-                np.testing.assert_allclose(Jq, Jo[q], rtol=1e-8, atol=1e-7)
+                assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
             bad += int(d.sum())
             total += int(active.sum())
     assert total > 200 and bad <= 0.05 * total, (bad, total)  # (and they stay rare: 0.8 % measured)
@@ -172,7 +177,7 @@ def test_tie_patches_follow_the_reference_in_reference_order_mode(ebo_ab, orc, m
                 c1.set_patches(sel, [0, len(sel)], [rects[q]])
                 r1, J1 = c1.eval(np.zeros((1, 2)))
             np.testing.assert_allclose(r1[0][0], ro[q], rtol=1e-12, atol=1e-9)
-            np.testing.assert_allclose(J1[0][0], Jo[q], rtol=1e-8, atol=1e-7)
+            assert_jac_close(J1[0][0], Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
             checked += 1
             ties += 1 if q in tie_q else 0
             others += 0 if q in tie_q else 1
