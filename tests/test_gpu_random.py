@@ -110,9 +110,11 @@ def test_edge_jacobian_at_exact_ties(ebo, ebo_ab, monkeypatch, orc):
     symmetric pixels have mathematically equal structure-tensor eigenvalues, so which of them is
     a window's argmax -- and therefore the Jacobian, not the value -- is decided by the rounding
     of the image sums, in the reference as here (the reference rounds once per event, the device
-    accumulates exactly).  The value always agrees; the Jacobian agrees except on a small
-    fraction of patches (0.8 % measured over 100 random windows)."""
-    bad = total = 0
+    accumulates exactly).  The value always agrees; the Jacobian agrees except on a fraction of the patches:
+    0.8 % differ by more than the 1e-7 ABSOLUTE of rounds 1-4, 10 % (28 of 282 here) by more than round 5's bound of 1e-8
+    of the patch's largest entry -- most tie flips move one window's small contribution.  Every one of them reproduces
+    the oracle when the device builds the image the reference's way."""
+    bad = coarse = total = 0
     for seed in range(200, 230):
         cs = random_case(seed)
         ev = ebo.make_events(cs["x"], cs["y"], cs["t"], cs["sign"])
@@ -132,8 +134,9 @@ def test_edge_jacobian_at_exact_ties(ebo, ebo_ab, monkeypatch, orc):
                 rq, Jq = reference_order_eval(ebo_ab, monkeypatch, cs, ev, c.patch_rect(q % c.npx, q // c.npx), 3)
                 assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
             bad += int(d.sum())
+            coarse += int(((np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-7).any(axis=1) & active.astype(bool)).sum())
             total += int(active.sum())
-    assert total > 200 and bad <= 0.05 * total, (bad, total)  # (and they stay rare: 0.8 % measured)
+    assert total > 200 and bad <= 0.15 * total and coarse <= 0.05 * total, (bad, coarse, total)
 
 
 def test_tie_patches_follow_the_reference_in_reference_order_mode(ebo_ab, orc, monkeypatch):
