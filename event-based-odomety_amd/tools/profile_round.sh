@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of a round on one MI355X (run through gpurun from the repo root):
-#   bash event-based-odomety_amd/tools/profile_round.sh r04
+#   bash event-based-odomety_amd/tools/profile_round.sh r05
 # Writes summaries under gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
 # Counter passes are separate runs (--pmc never together with traces), the program itself follows `--`.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O

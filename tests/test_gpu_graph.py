@@ -46,6 +46,36 @@ def test_recorded_evaluation_replays_bit_for_bit(ebo, synth, loss):
         torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+def test_recorded_large_edge_evaluation_takes_the_two_launch_path_and_replays(ebo, synth):
+    """Round 5: a batch above eight units per CU evaluates the edge loss in two launches (compact layout, then the
+    deferred units on a device-side list whose counter a hipMemsetAsync zeroes first): all three are recordable, and a
+    replay -- also with other flows in the same buffer, i.e. another split into the two classes -- has the direct call's bits."""
+    import torch
+    ev, offsets, gt = synth.make_stream(0, 24)
+    with ebo.Context(image_w=240, image_h=180, patch_w=20, patch_h=20, loss=ebo.LOSS_EDGE, tv_weight=0.0,
+                     max_events=len(ev), max_windows=24) as c:
+        c.set_windows(ev, offsets)
+        stream = torch.cuda.Stream()
+        c.set_stream(stream.cuda_stream)
+        torch.cuda.set_stream(stream)
+        d_flows = torch.from_numpy(gt * 0.9).to("cuda")
+        d_ref = torch.zeros((24 * c.P, 3), dtype=torch.float64, device="cuda")
+        d_out = torch.zeros_like(d_ref)
+        c.eval_device(d_flows.data_ptr(), 1, d_ref.data_ptr())  # also sizes the tables
+        torch.cuda.synchronize()
+        g = c.record(lambda: c.eval_device(d_flows.data_ptr(), 1, d_out.data_ptr()))
+        g.launch(2)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out, d_ref) and float(d_ref.abs().sum()) > 0
+        d_flows.mul_(0.2)  # small boxes now: (nearly) nothing is deferred
+        c.eval_device(d_flows.data_ptr(), 1, d_ref.data_ptr())
+        g.launch(1)
+        torch.cuda.synchronize()
+        assert torch.equal(d_out, d_ref)
+        g.close()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+
+
 def test_only_device_calls_can_be_recorded(ebo, synth):
     """Anything that copies through pageable memory, allocates or synchronises would invalidate the recording
     (and on ROCm 7.2 leave the stream unusable): such entry points refuse up front, the recording goes on, and

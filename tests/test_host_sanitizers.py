@@ -79,13 +79,13 @@ def test_parallel_events_txt_reader_equals_the_single_thread_reader():
     reader does (dataset_reader.h:33-97).  Against the single-thread reader of rounds 1-4 (kept in the test): the same
     events, count, byte offset and status for 24 mixed files (blank lines, comments, CRLF, exponents, signs, tabs,
     mantissas above 2^53, a malformed line, no trailing newline) x 1..16 threads x caps around the merge's edge cases
-    and chains of offsets, and a 10 M-line canonical file bit for bit -- also read in the reference's pieces of
+    and chains of offsets, and a 4 M-line canonical file bit for bit (10 M lines by hand: profiles/r05_text_ingest.txt) -- also read in the reference's pieces of
     1 000 000 lines; the rates are printed."""
     subprocess.check_call(["make", "-s", "-C", CPP, "txt_events_stress"])
-    text = _run_txt("txt_events_stress", 10_000_000)
+    text = _run_txt("txt_events_stress", 4_000_000)
     print(text[-900:])
 
 
 def test_parallel_events_txt_reader_under_thread_sanitizer():
     subprocess.check_call(["make", "-s", "-C", CPP, "txt_events_stress_tsan"])
-    _run_txt("txt_events_stress_tsan", 200_000)
+    _run_txt("txt_events_stress_tsan", 100_000)
