@@ -1,6 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-python event-based-odomety_amd/tools/ab_edge.py 0 256 "EBO_EDGE_ABLATE=512" "" "EBO_EDGE_ABLATE=512" ""
-python event-based-odomety_amd/tools/ab_edge.py 3 64 "EBO_EDGE_ABLATE=512" "" "EBO_EDGE_ABLATE=512" ""
-python event-based-odomety_amd/tools/ab_edge.py 2 64 "EBO_EDGE_ABLATE=512" "" "EBO_EDGE_ABLATE=512" ""
-python event-based-odomety_amd/tools/ab_edge.py 4 8 "EBO_EDGE_ABLATE=512" "" "EBO_EDGE_ABLATE=512" ""
+python event-based-odomety_amd/tools/ab_count.py 3 512 "EBO_COUNT_ALTERNATE=0" "" "EBO_COUNT_ALTERNATE=0" ""
+python event-based-odomety_amd/tools/ab_count.py 4 72 "EBO_COUNT_ALTERNATE=0" "" "EBO_COUNT_ALTERNATE=0" ""
+python event-based-odomety_amd/tools/ab_count.py 2 1536 "EBO_COUNT_ALTERNATE=0" "" 
