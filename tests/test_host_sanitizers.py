@@ -61,12 +61,12 @@ def test_host_lm_trajectories_keep_their_bits(no_avx2):
     assert "as pinned" in out.stdout
 
 
-def _run_txt(binary, lines):
+def _run_txt(binary, lines, *more):
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         env = dict(os.environ)
         env.setdefault("TSAN_OPTIONS", "halt_on_error=1")
-        out = subprocess.run([os.path.join(CPP, binary), d, str(lines)], env=env, capture_output=True, text=True, timeout=900)
+        out = subprocess.run([os.path.join(CPP, binary), d, str(lines)] + list(more), env=env, capture_output=True, text=True, timeout=900)
     text = out.stdout + out.stderr
     assert out.returncode == 0 and "txt_events_stress: OK" in out.stdout, text[-3000:]
     for bad in ("ThreadSanitizer", "AddressSanitizer", "runtime error"):
@@ -88,4 +88,4 @@ def test_parallel_events_txt_reader_equals_the_single_thread_reader():
 
 def test_parallel_events_txt_reader_under_thread_sanitizer():
     subprocess.check_call(["make", "-s", "-C", CPP, "txt_events_stress_tsan"])
-    _run_txt("txt_events_stress_tsan", 100_000)
+    _run_txt("txt_events_stress_tsan", 100_000, "quick")
