@@ -238,7 +238,35 @@ def run_children(cmd, env, deadline_s):
     a rank that never reaches a collective) must end as a failed run with a reason, below the time the driver gives a
     bench, not as a silent time-limit kill."""
     import signal
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def child_setup():
+        # the child leads its own session (so that its whole group can be ended), and must not outlive this process:
+        # if the parent is killed outright the kernel sends the child SIGTERM (torch.distributed.run then ends its ranks)
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(1, int(signal.SIGTERM))  # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True, preexec_fn=child_setup)
+
+    def forward(signum, _frame):  # a signal to the launcher ends the ranks too, then the launcher
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        try:
+            proc.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        sys.exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sg, forward)
+        except (ValueError, OSError):  # not the main thread
+            pass
     try:
         return proc.wait(timeout=deadline_s)
     except subprocess.TimeoutExpired:

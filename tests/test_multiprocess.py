@@ -216,3 +216,34 @@ def test_launcher_ends_children_that_outlive_its_deadline(tmp_path):
                   "import bench\n"
                   "sys.exit(bench.run_children([sys.executable, '-c', 'import sys; sys.exit(7)'], None, 30.0))\n" % ROOT)
     assert subprocess.run([sys.executable, str(ok)], capture_output=True, timeout=120).returncode == 7
+
+
+def test_launcher_takes_its_children_along_when_it_is_ended(tmp_path):
+    """The ranks run in their own session (so that their whole group can be ended at the deadline): a SIGTERM to the
+    launcher must therefore be passed on, or they would outlive it and keep their GPUs."""
+    import signal
+    import subprocess
+    import time
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mark = tmp_path / "child.pid"
+    child = tmp_path / "child.py"
+    child.write_text("import os, time\nopen(%r, 'w').write(str(os.getpid()))\ntime.sleep(600)\n" % str(mark))
+    driver = tmp_path / "driver.py"
+    driver.write_text("import sys\nsys.path.insert(0, %r)\nimport bench\n"
+                      "sys.exit(bench.run_children([sys.executable, %r], None, 300.0))\n" % (ROOT, str(child)))
+    p = subprocess.Popen([sys.executable, str(driver)])
+    t0 = time.time()
+    while not (mark.exists() and mark.read_text().strip()) and time.time() - t0 < 30:
+        time.sleep(0.05)
+    pid = int(mark.read_text())
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    for _ in range(100):
+        try:
+            os.kill(pid, 0)
+            time.sleep(0.05)
+        except ProcessLookupError:
+            break
+    else:
+        os.kill(pid, signal.SIGKILL)
+        raise AssertionError("the child outlived the launcher")
