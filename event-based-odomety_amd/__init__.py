@@ -324,6 +324,21 @@ def read_events_txt_threads(path, cap, threads=0, offset=None, out=None):
     return out[: n.value], (int(off.value) if off is not None else None), int(used.value)
 
 
+def read_events_txt8(path, cap, threads=0, offset=None):
+    """ebo_read_events_txt8: at most cap events as compact 8-byte records -> (records, base time in us, next offset or
+    None); every record's t_rel_us is relative to the base = the first event's time stamp of this call."""
+    out = np.zeros(cap, dtype=EVENT8_DTYPE)
+    n, base = C.c_size_t(), C.c_int64()
+    off = C.c_uint64(int(offset)) if offset is not None else None
+    f = lib().ebo_read_events_txt8
+    f.restype = C.c_int
+    rc = f(str(path).encode(), C.byref(off) if off is not None else None, _vp(out), C.c_size_t(cap), C.byref(n), C.byref(base),
+           C.c_int(int(threads)))
+    if rc:
+        raise EboError(rc, "cannot parse %s into compact records (%d events before the error)" % (path, n.value))
+    return out[: n.value], int(base.value), (int(off.value) if off is not None else None)
+
+
 def read_events_txt_at(path, offset, cap=1_000_000):
     """At most cap events of an events.txt from byte `offset` on -> (events, next offset): the pieces
     Davis240cReader::getEvents reads a recording in (EVENT_LENGTH lines per call)."""

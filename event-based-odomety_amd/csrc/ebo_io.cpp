@@ -152,6 +152,15 @@ int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, s
 	return ebo::txt::read_events_file(path, offset, out, cap, n, 0);
 }
 
+int ebo_read_events_txt8(const char* path, uint64_t* offset, ebo_event8* out, size_t cap, size_t* n, int64_t* t_base, int threads)
+{
+	if (!t_base || threads < 0)
+	{
+		return EBO_ERR_ARG;
+	}
+	return ebo::txt::read_events_file<ebo::txt::Sink8>(path, offset, out, cap, n, static_cast<unsigned>(threads), nullptr, t_base);
+}
+
 int ebo_read_events_txt_threads(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n, int threads,
 								int* threads_used)
 {

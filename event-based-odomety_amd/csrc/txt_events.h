@@ -167,16 +167,55 @@ inline const char* line_end(const char* p, const char* end)
 	return nl ? static_cast<const char*>(nl) : end;
 }
 
+// Where a parsed event goes: as it is (24 bytes, common::EventSample's layout), or as the compact 8-byte record of
+// include/ebo.h (ebo_event8: x:15 | polarity:1 | y:15 | 0:1, microseconds relative to a base time) that
+// ebo_set_windows8 takes -- text to device input with no 24-byte array in between.  A compact record that cannot hold
+// the event (a coordinate beyond +-16384, a time further than 2^31 us from the base) makes its line a malformed one.
+struct Sink24
+{
+	using Rec = ebo_event;
+	int64_t base = 0;
+	bool put(Rec& dst, const ebo_event& e) const
+	{
+		dst = e;
+		return true;
+	}
+};
+struct Sink8
+{
+	using Rec = ebo_event8;
+	int64_t base = 0;
+	bool put(Rec& dst, const ebo_event& e) const
+	{
+		const int64_t dt = e.t_us - base;
+		if (e.x < -16384 || e.x > 16383 || e.y < -16384 || e.y > 16383 || dt < INT32_MIN || dt > INT32_MAX)
+		{
+			return false;
+		}
+		dst.xy = (static_cast<uint32_t>(e.x) & 0x7FFFu) | (static_cast<uint32_t>(e.sign > 0 ? 1 : 0) << 15) |
+				 ((static_cast<uint32_t>(e.y) & 0x7FFFu) << 16);  // (ebo_internal.h: pack_lo)
+		dst.t_rel_us = static_cast<int32_t>(dt);
+		return true;
+	}
+};
+
 // The single-thread walk: at most cap events from `pos` on.  Returns the position behind the last line taken; a line
 // that holds an event beyond cap, or a malformed line (rc = EBO_ERR_RANGE), stays in front of it.
-inline const char* read_serial(const char* pos, const char* end, ebo_event* out, size_t cap, size_t& count, int& rc)
+template <class Sink>
+inline const char* read_serial(const char* pos, const char* end, typename Sink::Rec* out, size_t cap, size_t& count, int& rc,
+							   const Sink& sink)
 {
 	rc = EBO_OK;
 	while (pos < end)
 	{
 		const char* le = line_end(pos, end);
 		ebo_event ev;
-		const LineKind k = parse_line(pos, le, ev);
+		LineKind k = parse_line(pos, le, ev);
+		typename Sink::Rec rec;
+		if (k == kEvent && !sink.put(rec, ev))
+		{
+			k = kMalformed;
+		}
 		if (k == kMalformed)
 		{
 			rc = EBO_ERR_RANGE;
@@ -188,7 +227,7 @@ inline const char* read_serial(const char* pos, const char* end, ebo_event* out,
 			{
 				return pos;
 			}
-			out[count++] = ev;
+			out[count++] = rec;
 		}
 		pos = le < end ? le + 1 : end;
 	}
@@ -227,7 +266,8 @@ inline void count_lines(Chunk& c)
 }
 
 // out: the window's first slot; room: slots from there to the end of the caller's array
-inline void parse_chunk(Chunk& c, const char* fileEnd, ebo_event* out, size_t room)
+template <class Sink>
+inline void parse_chunk(Chunk& c, const char* fileEnd, typename Sink::Rec* out, size_t room, const Sink& sink)
 {
 	size_t slot = c.slot0;
 	const char* pos = c.begin;
@@ -235,7 +275,12 @@ inline void parse_chunk(Chunk& c, const char* fileEnd, ebo_event* out, size_t ro
 	{
 		const char* le = line_end(pos, fileEnd);
 		ebo_event ev;
-		const LineKind k = parse_line(pos, le, ev);
+		LineKind k = parse_line(pos, le, ev);
+		typename Sink::Rec rec;
+		if (k == kEvent && !sink.put(rec, ev))
+		{
+			k = kMalformed;
+		}
 		if (k == kMalformed)
 		{
 			c.stop = pos;
@@ -249,7 +294,7 @@ inline void parse_chunk(Chunk& c, const char* fileEnd, ebo_event* out, size_t ro
 				c.stop = pos;
 				break;
 			}
-			out[slot++] = ev;
+			out[slot++] = rec;
 		}
 		pos = le < fileEnd ? le + 1 : fileEnd;
 	}
@@ -281,9 +326,11 @@ inline void on_threads(unsigned T, F&& fn)
 }
 
 // At most cap events from `pos` on with up to `threads` threads; same results as read_serial.
-inline const char* read_parallel(const char* pos, const char* end, ebo_event* out, size_t cap, size_t& count, int& rc,
-								 unsigned threads, unsigned* threadsUsed = nullptr)
+template <class Sink>
+inline const char* read_parallel(const char* pos, const char* end, typename Sink::Rec* out, size_t cap, size_t& count, int& rc,
+								 unsigned threads, const Sink& sink, unsigned* threadsUsed = nullptr)
 {
+	using Rec = typename Sink::Rec;
 	rc = EBO_OK;
 	const size_t kMinChunk = static_cast<size_t>(256) << 10;  // below this a thread is not worth starting
 	if (threadsUsed)
@@ -309,7 +356,7 @@ inline const char* read_parallel(const char* pos, const char* end, ebo_event* ou
 		if (T <= 1)
 		{
 			// small input (or one thread): the serial walk over the window, then on if it was too short
-			const char* next = read_serial(pos, wEnd, out, cap, count, rc);
+			const char* next = read_serial(pos, wEnd, out, cap, count, rc, sink);
 			if (rc != EBO_OK || next < wEnd)
 			{
 				return next;  // malformed line, or cap reached in front of an event
@@ -345,9 +392,9 @@ inline const char* read_parallel(const char* pos, const char* end, ebo_event* ou
 			chunks[t].slot0 = before;
 			before += chunks[t].lines;
 		}
-		ebo_event* const first = out + count;
+		Rec* const first = out + count;
 		const size_t room = cap - count;
-		on_threads(T, [&chunks, end, first, room](unsigned t) { parse_chunk(chunks[t], end, first, room); });
+		on_threads(T, [&chunks, end, first, room, &sink](unsigned t) { parse_chunk(chunks[t], end, first, room, sink); });
 		// in file order: close the gaps that lines without an event left, stop at the first chunk that stopped
 		size_t have = 0;  // events of the window so far
 		for (unsigned t = 0; t < T; ++t)
@@ -355,7 +402,7 @@ inline const char* read_parallel(const char* pos, const char* end, ebo_event* ou
 			const Chunk& c = chunks[t];
 			if (c.events && c.slot0 != have)
 			{
-				std::memmove(first + have, first + c.slot0, c.events * sizeof(ebo_event));
+				std::memmove(first + have, first + c.slot0, c.events * sizeof(Rec));
 			}
 			have += c.events;
 			if (c.stop)
@@ -369,7 +416,7 @@ inline const char* read_parallel(const char* pos, const char* end, ebo_event* ou
 				// no room at the slot the chunk had counted up to: with lines that held no event before it there may be
 				// room after all -- the serial walk goes on from the line the chunk stopped at (at most as many events
 				// as there were such lines), and it is also what consumes blank lines behind the last event taken
-				return read_serial(c.stop, end, out, cap, count, rc);
+				return read_serial(c.stop, end, out, cap, count, rc, sink);
 			}
 		}
 		count += have;
@@ -378,7 +425,7 @@ inline const char* read_parallel(const char* pos, const char* end, ebo_event* ou
 	if (count >= cap && pos < end)
 	{
 		// cap == 0, or cap reached exactly at a window's end: blank lines behind it are still consumed
-		return read_serial(pos, end, out, cap, count, rc);
+		return read_serial(pos, end, out, cap, count, rc, sink);
 	}
 	return pos;
 }
@@ -433,8 +480,9 @@ struct Mapping
 
 // at most cap events from byte *offset of the file on (null: from the start); *offset moves behind the last line
 // taken; threads == 0: EBO_HOST_THREADS or the machine's hardware threads
-inline int read_events_file(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n, unsigned threads,
-							unsigned* threadsUsed = nullptr)
+template <class Sink = Sink24>
+inline int read_events_file(const char* path, uint64_t* offset, typename Sink::Rec* out, size_t cap, size_t* n, unsigned threads,
+							unsigned* threadsUsed = nullptr, int64_t* baseOut = nullptr)
 {
 	if (!path || !n || (cap && !out))
 	{
@@ -455,7 +503,30 @@ inline int read_events_file(const char* path, uint64_t* offset, ebo_event* out, 
 	const char* end = begin + map.size;
 	size_t count = 0;
 	int rc = EBO_OK;
-	const char* pos = read_parallel(begin + start, end, out, cap, count, rc, threads ? threads : thread_budget(), threadsUsed);
+	Sink sink;
+	if (baseOut)
+	{
+		// the base time of compact records: the first event's time stamp of this call (a short serial look-ahead; blank
+		// lines in front of it are skipped, a malformed line there is found again -- and reported -- by the walk itself)
+		sink.base = 0;
+		for (const char* q = begin + start; q < end;)
+		{
+			const char* le = line_end(q, end);
+			ebo_event ev;
+			const LineKind k = parse_line(q, le, ev);
+			if (k == kEvent)
+			{
+				sink.base = ev.t_us;
+			}
+			if (k != kBlank)
+			{
+				break;
+			}
+			q = le < end ? le + 1 : end;
+		}
+		*baseOut = sink.base;
+	}
+	const char* pos = read_parallel(begin + start, end, out, cap, count, rc, threads ? threads : thread_budget(), sink, threadsUsed);
 	*n = count;
 	if (offset)
 	{

@@ -503,6 +503,12 @@ int ebo_read_events_txt_at(const char* path, uint64_t* offset, ebo_event* out, s
  * how many threads parsed (threads_used, may be NULL). */
 int ebo_read_events_txt_threads(const char* path, uint64_t* offset, ebo_event* out, size_t cap, size_t* n, int threads,
 								int* threads_used);
+/* The same reader writing the compact 8-byte records ebo_set_windows8 takes (a third of the bytes; no 24-byte array
+ * between the text and the device): *t_base = the time stamp of the first event of THIS call, every record's t_rel_us is
+ * relative to it -- pass it as t_base[w] of every window cut from the call's events.  offset may be NULL (from the start);
+ * threads 0 = the default.  EBO_ERR_RANGE also for an event a compact record cannot hold (a coordinate beyond +-16384, a
+ * time further than 2^31 us from the base): it stays in front of that line, as for a malformed one. */
+int ebo_read_events_txt8(const char* path, uint64_t* offset, ebo_event8* out, size_t cap, size_t* n, int64_t* t_base, int threads);
 
 /* Contiguous shard [begin,end) of n_units for rank of world (multi-GPU, §8e). */
 int ebo_shard_range(int n_units, int rank, int world, int* begin, int* end);

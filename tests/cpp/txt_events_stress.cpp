@@ -264,6 +264,95 @@ int main(int argc, char** argv)
 		std::printf("mixed files: %d files x %zu thread counts x 8 caps + offset chains compared\n", k, threadCounts.size());
 	}
 
+	// 1b. compact 8-byte records straight from the text (Sink8): the records ebo_pack_events8 makes of the 24-byte reader's
+	// events with the first event's time as the base; an event a compact record cannot hold ends the result like a
+	// malformed line does
+	{
+		const std::string path = dir + "/compact.txt";
+		std::vector<size_t> lineStart;
+		const size_t lines = quick ? 60000 : 400000;
+		{
+			FILE* fp = std::fopen(path.c_str(), "wb");
+			double t = 17.25;
+			size_t at = 0;
+			for (size_t i = 0; i < lines; ++i)
+			{
+				t += static_cast<double>(rnd() % 61) * 1e-6;
+				lineStart.push_back(at);
+				int w;
+				if (i % 97 == 5)
+				{
+					w = std::fprintf(fp, "\r\n");
+				}
+				else
+				{
+					w = std::fprintf(fp, "%.6f %u %u %u%s", t, static_cast<unsigned>(rnd() % 1280), static_cast<unsigned>(rnd() % 720),
+									 static_cast<unsigned>(rnd() & 1), (i % 5 == 0) ? "\r\n" : "\n");
+				}
+				at += static_cast<size_t>(w);
+			}
+			std::fclose(fp);
+		}
+		std::vector<ebo_event> a(lines);
+		size_t na = 0;
+		uint64_t oa = 0;
+		EXPECT_TRUE(ebo::txt::read_events_file(path.c_str(), &oa, a.data(), a.size(), &na, 1) == EBO_OK && na > lines * 9 / 10);
+		for (unsigned threads : {1u, 3u, 8u})
+		{
+			for (size_t cap : {na, na / 2 + 7, static_cast<size_t>(4096)})
+			{
+				std::vector<ebo_event8> b(cap + 1);
+				size_t nb = 0;
+				uint64_t ob = 0;
+				int64_t base = -1;
+				const int rc = ebo::txt::read_events_file<ebo::txt::Sink8>(path.c_str(), &ob, b.data(), cap, &nb, threads, nullptr, &base);
+				std::vector<ebo_event> ref(cap + 1);
+				size_t nr = 0;
+				uint64_t orf = 0;
+				const int rr = ebo::txt::read_events_file(path.c_str(), &orf, ref.data(), cap, &nr, 1);
+				bool same = rc == rr && nb == nr && ob == orf && base == a[0].t_us;
+				for (size_t i = 0; same && i < nb; ++i)
+				{
+					const ebo_event& e = ref[i];
+					const uint32_t xy = (static_cast<uint32_t>(e.x) & 0x7FFFu) | (static_cast<uint32_t>(e.sign > 0) << 15) |
+										((static_cast<uint32_t>(e.y) & 0x7FFFu) << 16);
+					same = b[i].xy == xy && b[i].t_rel_us == static_cast<int32_t>(e.t_us - base);
+				}
+				EXPECT_TRUE(same);
+			}
+		}
+		// line 1234 gets a coordinate no compact record holds: the events before it, EBO_ERR_RANGE, the offset in front of it
+		{
+			const std::string bad = dir + "/compact_bad.txt";
+			FILE* fp = std::fopen(bad.c_str(), "wb");
+			size_t at = 0, badAt = 0, before = 0;
+			for (size_t i = 0; i < 3000; ++i)
+			{
+				if (i == 1234)
+				{
+					badAt = at;
+					at += static_cast<size_t>(std::fprintf(fp, "0.500000 20000 3 1\n"));
+				}
+				else
+				{
+					at += static_cast<size_t>(std::fprintf(fp, "0.%06zu %zu %zu 0\n", i, i % 640, i % 480));
+					before += i < 1234;
+				}
+			}
+			std::fclose(fp);
+			for (unsigned threads : {1u, 8u})
+			{
+				std::vector<ebo_event8> b(4000);
+				size_t nb = 0;
+				uint64_t ob = 0;
+				int64_t base = -1;
+				const int rc = ebo::txt::read_events_file<ebo::txt::Sink8>(bad.c_str(), &ob, b.data(), b.size(), &nb, threads, nullptr, &base);
+				EXPECT_TRUE(rc == EBO_ERR_RANGE && nb == before && ob == badAt && base == 0);
+			}
+		}
+		std::printf("compact records: %zu lines, 3 thread counts x 3 caps, and the out-of-range line\n", lines);
+	}
+
 	// 2. the large canonical file: bit-identical, and the rates
 	{
 		const std::string path = dir + "/large.txt";

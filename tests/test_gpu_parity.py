@@ -595,3 +595,33 @@ def test_pipelined_lock_step_solve_equals_the_plain_one(ebo_ab, synth, monkeypat
             alone, s1 = c.solve(opts)
         np.testing.assert_allclose(alone[0], out[0][0][w], rtol=0, atol=1e-7)
         assert s1[0].iterations == out[0][1][w][0]
+
+
+def test_text_to_device_through_compact_records(ebo, synth, tmp_path):
+    """Round 5: ebo_read_events_txt8 parses an events.txt straight into the 8-byte records ebo_set_windows8 takes (base time =
+    the first event's): the windows loaded that way -- unit tables, objective, Jacobian, count images -- are those of the
+    24-byte path (ebo_read_events_txt + ebo_set_windows) bit for bit."""
+    ev, offsets, gt = synth.make_stream(0, 3)
+    p = tmp_path / "events.txt"
+    with open(p, "w") as f:
+        f.write("".join("%d.%06d %d %d %d\n" % (t // 1000000, t % 1000000, x, y, 1 if s > 0 else 0)
+                        for t, x, y, s in zip(ev["t_us"].tolist(), ev["x"].tolist(), ev["y"].tolist(), ev["sign"].tolist())))
+    ev24 = ebo.read_events_txt(str(p), cap=len(ev) + 8)
+    # seconds -> double -> x 1e6 -> truncation, as the reference's reader does: a microsecond may be lost on the way in
+    assert np.abs(ev24["t_us"] - ev["t_us"]).max() <= 1 and np.array_equal(ev24["x"], ev["x"]) and np.array_equal(ev24["sign"], ev["sign"])
+    ev8, base, off = ebo.read_events_txt8(str(p), len(ev) + 8, threads=3, offset=0)
+    assert len(ev8) == len(ev) and base == int(ev24["t_us"][0]) and off == os.path.getsize(p)
+    assert np.array_equal(ev8, ebo.pack_events8(ev24, base))
+    flows = gt * 0.4
+    with ebo.Context(loss=ebo.LOSS_VARIANCE, tv_weight=0.0, max_events=len(ev), max_windows=3) as a, \
+            ebo.Context(loss=ebo.LOSS_VARIANCE, tv_weight=0.0, max_events=len(ev), max_windows=3) as b:
+        a.set_windows(ev24, offsets)
+        b.set_windows8(ev8, [base] * 3, offsets)
+        ra, Ja = a.eval(flows)
+        rb, Jb = b.eval(flows)
+        assert np.array_equal(ra, rb) and np.array_equal(Ja, Jb)
+        for mode in (ebo.COUNT_INTEGRATED, ebo.COUNT_WARPED):
+            assert np.array_equal(a.count_image(mode, flows if mode == ebo.COUNT_WARPED else None),
+                                  b.count_image(mode, flows if mode == ebo.COUNT_WARPED else None))
+        for q in range(a.P):
+            assert a.patch_info(q, 1) == b.patch_info(q, 1)

@@ -90,7 +90,7 @@ def test_random_windows_match_the_oracle(ebo, ebo_ab, monkeypatch, orc, seed):
                     for q in np.flatnonzero(tie):
                         rq, Jq = reference_order_eval(ebo_ab, monkeypatch, cs, ev, c.patch_rect(q % c.npx, q // c.npx), p.min_events)
                         np.testing.assert_allclose(rq, ro[q], rtol=1e-12, atol=1e-9)
-                        assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
+                        assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5, floor=5e-8)  # a tie patch in reference-order mode
                     continue
                 if loss == ebo.LOSS_EDGE:
                     assert_jac_close(J[0], Jo, rtol=tol)
@@ -132,7 +132,7 @@ def test_edge_jacobian_at_exact_ties(ebo, ebo_ab, monkeypatch, orc):
             # every patch that differs is a tie of the image sums' last bits: built the reference's way, it agrees
             for q in np.flatnonzero(d):
                 rq, Jq = reference_order_eval(ebo_ab, monkeypatch, cs, ev, c.patch_rect(q % c.npx, q // c.npx), 3)
-                assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
+                assert_jac_close(Jq, Jo[q], rtol=1e-8, patch_rel=1e-5, floor=5e-8)  # a tie patch in reference-order mode
             bad += int(d.sum())
             coarse += int(((np.abs(J[0] - Jo) > 1e-8 * np.abs(Jo) + 1e-7).any(axis=1) & active.astype(bool)).sum())
             total += int(active.sum())
@@ -180,7 +180,7 @@ def test_tie_patches_follow_the_reference_in_reference_order_mode(ebo_ab, orc, m
                 c1.set_patches(sel, [0, len(sel)], [rects[q]])
                 r1, J1 = c1.eval(np.zeros((1, 2)))
             np.testing.assert_allclose(r1[0][0], ro[q], rtol=1e-12, atol=1e-9)
-            assert_jac_close(J1[0][0], Jo[q], rtol=1e-8, patch_rel=1e-5)  # a tie patch in reference-order mode
+            assert_jac_close(J1[0][0], Jo[q], rtol=1e-8, patch_rel=1e-5, floor=5e-8)  # a tie patch in reference-order mode
             checked += 1
             ties += 1 if q in tie_q else 0
             others += 0 if q in tie_q else 1
