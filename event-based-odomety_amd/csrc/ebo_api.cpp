@@ -318,14 +318,19 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 		if (eligible && wantFull)
 		{
 			const size_t budget = ab_size("EBO_EDGE_COMPACT_KB", 52) * 1024;
-			// red[128 doubles] | 80 ints | list (one int per 4 pixels + slack) | I, E (8 B each) | 4-bit counters
-			size_t cap = (budget - 168 * sizeof(double) - 64 * sizeof(int)) * 2 / 35;  // 17.5 B per pixel
-			cap = std::min(cap & ~static_cast<size_t>(7), (canvasPx + 7) & ~static_cast<size_t>(7));
-			const size_t listCap = ((cap / 4 + 64) + 1) & ~static_cast<size_t>(1);
-			const size_t bytes = (168 + listCap / 2) * sizeof(double) + cap * 16 + cap / 2;
+			// red[128 doubles] | 80 ints | list (one int per 4 pixels + slack) | I (8 B per STORED pixel: the rows with
+			// taps) | E (8 B per pixel of the box) | 4-bit counters.  A box fits when its arrays fit the bytes of `cap`
+			// untrimmed pixels (16.5 B each) and it has at most maxPx pixels -- what the list and the direction table
+			// are laid out for: no box of more than budget / 13 pixels can fit (I stores at least half of its rows).
+			const size_t maxPx = std::min((canvasPx + 7) & ~static_cast<size_t>(7), (budget / 13) & ~static_cast<size_t>(7));
+			const size_t listCap = ((maxPx / 4 + 64) + 1) & ~static_cast<size_t>(1);
+			const size_t hdrBytes = (168 + listCap / 2) * sizeof(double);
+			size_t cap = budget > hdrBytes ? ((budget - hdrBytes) * 2 / 33) & ~static_cast<size_t>(7) : 0;
+			cap = std::min(cap, maxPx);
+			const size_t bytes = hdrBytes + cap * 16 + cap / 2;
 			if (cap >= 1024 && bytes <= budget)
 			{
-				L.compact_table_px = static_cast<int>(cap);
+				L.compact_table_px = static_cast<int>(maxPx);
 			}
 			if (cap >= 1024 && bytes <= budget && want)
 			{
@@ -356,7 +361,10 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	}
 	L.scratch_stride = (canvasPx * (bytesPerPx + 1) + 256 + 255) & ~static_cast<size_t>(255);  // I, E, A, cnt + the argmax list (canvasPx / 4 + 64 ints)
 	L.d_scratch = nullptr;
-	if (static_cast<size_t>(L.cap_px) < canvasPx)
+	// the most pixels an LDS-resident box of the aliased layouts may have: what the argmax list (2048 ints, the last 128
+	// of them the device-resident solver's state; a window per four pixels) and a slot of the direction table hold
+	const size_t maxLdsPx = std::min<size_t>(canvasPx, 4 * (2048 - 128 - 64));
+	if (static_cast<size_t>(L.cap_px) < canvasPx || maxLdsPx < canvasPx)
 	{
 		// some box could exceed LDS: keep a global slice per (set, unit)
 		const size_t need = L.scratch_stride * static_cast<size_t>(L.wg_slots);
@@ -431,12 +439,12 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 	// L2 / Infinity Cache): spares every argmax entry the re-derivation of its tensor sums.  Beyond 4 GiB
 	// (EBO_EDGE_CS_MB) the reverse pass re-derives them instead.
 	L.ec.cs = nullptr;
-	L.ec.cs_stride = L.cap_px;
+	L.ec.cs_stride = static_cast<int>(L.alias_lds ? maxLdsPx : static_cast<size_t>(L.cap_px));
 	{
 		// (the compact launch keys its slots by unit, one workgroup each: the larger of the two launches' tables)
 		// (sized by the context's units, not by this launch's window list: the rounds of a lock-step solve must not
 		// flip between two sizes -- a reallocation synchronises the device)
-		const size_t need = std::max(static_cast<size_t>(L.wg_slots) * L.cap_px,
+		const size_t need = std::max(static_cast<size_t>(L.wg_slots) * L.ec.cs_stride,
 									 L.compact_table_px > 0 ? static_cast<size_t>(L.n_units) * L.compact_table_px : 0) * 2 * sizeof(double);
 		// The table is an optimisation nobody asked for by name, so it must not surprise: at most
 		// EBO_EDGE_CS_MB (default 4096) AND at most a quarter of the memory that is free right now

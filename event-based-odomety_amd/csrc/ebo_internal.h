@@ -181,7 +181,7 @@ struct EdgeConsts
 	double mean_threshold; // 1e-4 (:159)
 	int ablate;            // timing-only ablation mask (EBO_EDGE_ABLATE): 1 eigen, 2 NMS, 4 reverse, 8 gather, 16 scatter, 32 no register runs, 64 reference-order image, 128 bank-spread fake entries in the reverse sweep
 	double* cs;            // DEVICE table [workgroup slot][cap_px][2] or null: (s00 - s11)/d and 2 s01/d of every pixel with a positive eigenvalue, written by the eigenvalue pass of a Jacobian evaluation, read by its reverse pass for the argmax pixels (null: the reverse pass re-derives the tensor sums)
-	int cs_stride;         // pixels per unit in cs (= cap_px)
+	int cs_stride;         // pixels per slot of cs = the most pixels an LDS-resident box may have (aliased layouts)
 	int reserved;          // tensor filter forms (EBO_EDGE_SEPARABLE): 1 band buffers on the 28 B layout, 2 register runs on the 20 B layout, 4 register runs on the 28 B layout
 	unsigned long long* stats;  // null, or DEVICE counters [6] of ebo_edge_work_stats: units past the penalty test, their events, box pixels, eigenvalue-region pixels, NMS windows, argmax entries
 };

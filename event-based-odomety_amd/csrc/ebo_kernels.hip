@@ -3636,7 +3636,7 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 				return -2;
 			}
 			EdgeConsts ecCompact = L.ec;
-			ecCompact.cs_stride = L.compact_cap_px;  // one slot per unit, as in rounds 1-4
+			ecCompact.cs_stride = L.compact_table_px;  // one slot per unit, as in rounds 1-4; the most pixels a box of this launch may have
 			hipLaunchKernelGGL(wide, dim3(nItemsX, 1), dim3(256), L.compact_lds_bytes, s, L.d_events, L.d_units, L.d_flows,
 							   L.want_jac, L.compact_cap_px, L.fd_step, L.d_scratch, L.scratch_stride, L.d_sets, L.d_out, L.c, ecCompact,
 							   L.d_modes, live, L.compact);
