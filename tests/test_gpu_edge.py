@@ -304,3 +304,23 @@ def test_edge_large_batch_takes_the_compact_path_by_itself(ebo, orc, synth):
         for w in (0, 17):
             ro, Jo, _, _ = orc.window_eval(ev[offsets[w]:offsets[w + 1]], oparams(orc, c.params), flows[w])
             check_rj(r[w], J[w], ro, Jo)
+
+
+@pytest.mark.parametrize("config,windows", [(0, 2), (3, 1)])
+def test_edge_image_rows_stored_for_the_taps_only(ebo, orc, synth, config, windows):
+    """Round 5: I is stored for the rows that hold taps plus one zero row on either side, every stencil read clamps its
+    row into them.  Uniform flows that push every patch's events against each border of its 3W x 3H canvas (the stored
+    rows then end at the canvas edge, where there is no zero row) and a diagonal one, value and Jacobian against the
+    oracle; the value-only launch gives the same value bits."""
+    ev, offsets, gt = synth.make_stream(config, windows)
+    with ctx_for(ebo, synth, config, tv_weight=0.0, max_events=len(ev), max_windows=windows) as c:
+        c.set_windows(ev, offsets)
+        prm = oparams(orc, c.params)
+        for m in ((0.9, 0.0), (-0.9, 0.0), (0.0, 0.9), (0.0, -0.9), (0.8, -0.8), (0.05, 0.02)):
+            flows = np.tile(np.array(m), (windows, c.P, 1)) + 0.3 * gt
+            r, J = c.eval(flows)
+            v, _ = c.eval(flows, want_jac=False)
+            assert np.array_equal(r, v)
+            for w in range(windows):
+                ro, Jo, _, _ = orc.window_eval(ev[offsets[w]:offsets[w + 1]], prm, flows[w])
+                check_rj(r[w], J[w], ro, Jo)
