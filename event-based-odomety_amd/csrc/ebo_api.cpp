@@ -334,7 +334,8 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 			}
 			if (cap >= 1024 && bytes <= budget && want)
 			{
-				if (c->edge_defer_cap < items + 1)
+				const size_t listInts = (items + 3) & ~static_cast<size_t>(3);
+				if (c->edge_defer_cap < items)
 				{
 					if (c->d_edge_defer)
 					{
@@ -343,17 +344,20 @@ int edge_launch_setup(ebo_ctx* c, EdgeLaunch& L)
 						c->d_edge_defer = nullptr;
 						c->edge_defer_cap = 0;
 					}
-					int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_edge_defer), (items + 1) * sizeof(int)), "hipMalloc edge deferred list");
+					int rc = c->hip(hipMalloc(reinterpret_cast<void**>(&c->d_edge_defer), (4 + listInts) * sizeof(int) + items * 4 * sizeof(int)),
+									"hipMalloc edge deferred list");
 					if (rc)
 					{
 						return rc;
 					}
-					c->edge_defer_cap = items + 1;
+					c->edge_defer_cap = items;
 				}
 				L.compact.hdr_doubles = static_cast<int>(168 + listCap / 2);
 				L.compact.list_cap = static_cast<int>(listCap);
 				L.compact.defer_count = c->d_edge_defer;
-				L.compact.defer_list = c->d_edge_defer + 1;
+				L.compact.defer_list = c->d_edge_defer + 4;
+				// (behind the list as laid out for THIS context's items: the allocation may be larger, the offsets are this launch's)
+				L.compact.bbox = ab_size("EBO_EDGE_CLASSIFY", 1) ? static_cast<void*>(c->d_edge_defer + 4 + listInts) : nullptr;
 				L.compact_cap_px = static_cast<int>(cap);
 				L.compact_lds_bytes = bytes;
 			}

@@ -92,8 +92,10 @@ struct ebo_ctx
 	unsigned long long* edge_stats_dev = nullptr;  // set only while ebo_edge_work_stats runs its one evaluation
 	double* d_edge_cs = nullptr;     // eigenvector directions of the edge loss's eigenvalue pass, [workgroup slot][cap_px][2]
 	int n_cus = 0;                   // compute units of the device (0: not asked yet)
-	int* d_edge_defer = nullptr;     // [1 + items]: length, then the units the compact launch deferred to the 20 B layout
-	size_t edge_defer_cap = 0;       // ints
+	// the compact path's per-launch tables in one allocation: int length (+ 3 ints of padding) | int list[items] (the
+	// units whose arrays do not fit the compact layout) | int4 bbox[items] (k_edge_classify's tap bounding boxes)
+	int* d_edge_defer = nullptr;
+	size_t edge_defer_cap = 0;       // items
 	size_t edge_cs_cap = 0;          // bytes
 	void* d_edge_scratch = nullptr;  // edge-loss fallback arrays
 	size_t edge_scratch_cap = 0;

@@ -196,6 +196,7 @@ struct EdgeCompact
 	int list_cap = 0;          // ints of the list / cell region
 	int* defer_list = nullptr; // DEVICE [items]
 	int* defer_count = nullptr;// DEVICE, zeroed before the launch
+	void* bbox = nullptr;      // DEVICE int4[items]: the tap bounding boxes of this launch's units (k_edge_classify), or null
 };
 
 struct EdgeLaunch

@@ -3620,13 +3620,16 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 		ka.nSets = L.flow_sets;
 		ka.itemList = nullptr;
 		ka.itemCount = nullptr;
+		ka.bbox = nullptr;
 		if (L.compact.list_cap > 0 && L.alias_lds && L.flow_sets == 1)
 		{
 			// Two launches (round 5).  First every unit on the COMPACT layout, three 256-lane workgroups per CU (the
 			// 168-VGPR instantiation); a unit whose box does not fit goes on the deferred list.  Then the deferred
 			// units on the 20 B layout, two per CU, persistent workgroups that read the list's length on the device.
 			using WideKern = decltype(&k_eval_edge_wg<true, true, 768>);
-			WideKern wide = L.want_jac ? k_eval_edge_wg<true, true, 768> : k_eval_edge_wg<true, false, 768>;
+			int4* const bbox = static_cast<int4*>(L.compact.bbox);
+			WideKern wide = bbox ? (L.want_jac ? k_eval_edge_wg<true, true, 768, true> : k_eval_edge_wg<true, false, 768, true>)
+								 : (L.want_jac ? k_eval_edge_wg<true, true, 768> : k_eval_edge_wg<true, false, 768>);
 			if (allow_big_lds(wide, L.compact_lds_bytes))
 			{
 				return -2;
@@ -3637,15 +3640,26 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 			}
 			EdgeConsts ecCompact = L.ec;
 			ecCompact.cs_stride = L.compact_table_px;  // one slot per unit, as in rounds 1-4; the most pixels a box of this launch may have
+			if (bbox)
+			{
+				// the bounding-box pass of every unit, and the list of the second launch, in one small kernel up front
+				hipLaunchKernelGGL(k_edge_classify, dim3((nItemsX + 15) / 16), dim3(1024), 0, s, L.d_events, L.d_units, L.d_flows, L.d_modes,
+								   live, nItemsX, L.compact_cap_px, L.compact_table_px, L.c, bbox, L.compact.defer_list, L.compact.defer_count);
+				if (check_launch())
+				{
+					return -2;
+				}
+			}
 			hipLaunchKernelGGL(wide, dim3(nItemsX, 1), dim3(256), L.compact_lds_bytes, s, L.d_events, L.d_units, L.d_flows,
 							   L.want_jac, L.compact_cap_px, L.fd_step, L.d_scratch, L.scratch_stride, L.d_sets, L.d_out, L.c, ecCompact,
-							   L.d_modes, live, L.compact);
+							   L.d_modes, live, L.compact, bbox);
 			if (check_launch())
 			{
 				return -2;
 			}
 			ka.itemList = L.compact.defer_list;
 			ka.itemCount = L.compact.defer_count;
+			ka.bbox = bbox;
 		}
 		const int grid = std::min(nItemsX * L.flow_sets, std::max(L.wg_slots, 1));  // persistent workgroups
 		hipLaunchKernelGGL(edgeKern, dim3(grid), dim3(L.block), L.lds_bytes, s, ka);
@@ -3661,7 +3675,7 @@ int launch_eval_edge(const EdgeLaunch& L, void* stream)
 		}
 		hipLaunchKernelGGL(edgeKern, dim3(nItemsX, L.flow_sets), dim3(L.block), L.lds_bytes, s, L.d_events, L.d_units, L.d_flows,
 						   L.want_jac, L.cap_px, L.fd_step, L.d_scratch, L.scratch_stride, L.d_sets, L.d_out, L.c, L.ec,
-						   L.flow_sets == 1 ? L.d_modes : nullptr, live, EdgeCompact());
+						   L.flow_sets == 1 ? L.d_modes : nullptr, live, EdgeCompact(), static_cast<const int4*>(nullptr));
 	}
 	if (check_launch())
 	{
