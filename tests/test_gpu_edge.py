@@ -285,9 +285,16 @@ def test_edge_compact_layout_and_deferred_units_keep_the_bits(ebo_ab, orc, synth
             r1, J1 = c.eval(flows)
             v1, _ = c.eval(flows, want_jac=False)
             r2, J2 = c.eval(flows)  # and run to run
+            # ... and with the bounding boxes and the second launch's list made inside the compact launch (as until
+            # k_edge_classify made them up front)
+            monkeypatch.setenv("EBO_EDGE_CLASSIFY", "0")
+            r3, J3 = c.eval(flows)
+            v3, _ = c.eval(flows, want_jac=False)
+            monkeypatch.delenv("EBO_EDGE_CLASSIFY")
             monkeypatch.delenv("EBO_EDGE_COMPACT_KB")
             assert np.array_equal(r0, r1) and np.array_equal(J0, J1, equal_nan=True), scale
             assert np.array_equal(v0, v1) and np.array_equal(r1, r2) and np.array_equal(J1, J2, equal_nan=True), scale
+            assert np.array_equal(r3, r1) and np.array_equal(J3, J1, equal_nan=True) and np.array_equal(v3, v1), scale
             if scale in (0.5, 1.0):
                 ro, Jo, _, _ = orc.window_eval(ev[offsets[0]:offsets[1]], oparams(orc, c.params), flows[0])
                 check_rj(r1[0], J1[0], ro, Jo)
