@@ -1,6 +1,6 @@
 #!/bin/bash
 # k_edge_classify (the bounding-box pass and the second launch's list in one small kernel up front) on / off, A/B build;
-# bits of the new build against libebo_hip_base.so first
+# bits of the new build against libebo_hip_base.so first (see tools/ab/edge_trim_ab.sh for how that library is built)
 set -e
 cd $GRAFT_REPO_ROOT
 T=event-based-odomety_amd/tools

@@ -1,6 +1,8 @@
 #!/bin/bash
-# I stored for the rows with taps only (round 5, late): bits against the build before it (libebo_hip_base.so = HEAD's
-# sources with -DEBO_AB), then timings of the two builds, twice
+# I stored for the rows with taps only (round 5, late): bits against the build before it, then timings of the two builds,
+# twice.  libebo_hip_base.so = the sources of the commit to compare with, built beside the tree's own libraries:
+#   git stash / git worktree of that commit; make -C event-based-odomety_amd/csrc ../libebo_hip_base.so OUT=../libebo_hip_base.so \
+#        OBJDIR=build_base FLAGS="-std=c++17 -O3 -fPIC -ffp-contract=off -DEBO_AB"   (not kept in the tree)
 set -e
 cd $GRAFT_REPO_ROOT
 T=event-based-odomety_amd/tools
